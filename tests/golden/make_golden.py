@@ -1,0 +1,370 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Build-container only (needs /root/reference).  Run as
+
+    cd /root/repo && PYTHONHASHSEED=0 python tests/golden/make_golden.py
+
+PYTHONHASHSEED=0 matters: the reference's subtask order comes from iterating a
+Python ``set`` of Action objects (recipe_planner/stripsworld.py:72-77,
+envs/overcooked_environment.py:457), so it changes with the hash seed.  Every
+fixture records the order it was generated with.
+
+Fixtures (all ``.npz``, compressed, a few hundred KB in total):
+
+  base_<level>_a<A>.npz     gym_cooking.envs.OvercookedEnvironment.step/reset
+                            (overcooked_environment.py:180-241): per step the
+                            action codes fed in and the full post-step state,
+                            reward, done, completed_subtasks, goal_objects_count
+                            and the raw fp64 bits of both shaping terms.
+  wrap_<name>.npz           gym_comm OvercookedMultiEnv.multi_step/multi_reset
+                            (gym_comm/envs/overcooked_env.py:207-297): per step
+                            the 11 observation fields of both viewers, the raw
+                            fp64 bits of the shaped reward, done.
+
+Action codes used in the tapes: 0=(0,1) 1=(0,-1) 2=(-1,0) 3=(1,0) 4=(0,0)
+(0..3 are World.NAV_ACTIONS in order, utils/world.py:16).
+"""
+import json
+import os
+import random
+import sys
+from collections import deque
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as H  # noqa: E402
+
+NAV = [(0, 1), (0, -1), (-1, 0), (1, 0), (0, 0)]
+LETTER = {"D": 0, "U": 1, "L": 2, "R": 3, "N": 4}
+
+
+def codes(s):
+    return [LETTER[c] for c in s]
+
+
+# ---- known-answer scripts ----------
+KAT1_TOMATO = list(zip(codes("DDDRR" + "N" * 18), codes("RULLLLLDDDDRRRRDLLLLUUL")))
+KAT2_SALAD = [(LETTER[a], LETTER[b]) for a, b in [
+    "NR", "NU", "NL", "NL", "RR", "LR", "LL", "UL", "RD", "RD", "LD", "LD",
+    "UR", "DR", "DL", "DL", "DN", "RN", "RN", "LN", "UN", "UN", "LN"]]
+
+
+# ---- a purposeful random policy, so tapes reach chops/merges/deliveries ----
+class Purposeful:
+    """Each agent repeatedly picks a random non-floor target cell next to a
+    reachable floor cell, walks to it along a BFS path over floor cells (other
+    agents ignored, so collisions happen), presses into it, and re-targets.
+    With probability eps an action is replaced by a uniform 5-way draw."""
+
+    def __init__(self, cells, n_agents, rng, eps=0.1):
+        self.cells = cells
+        self.h = len(cells)
+        self.w = len(cells[0])
+        self.rng = rng
+        self.eps = eps
+        self.plan = [deque() for _ in range(n_agents)]
+        self.targets = []
+        for y in range(self.h):
+            for x in range(self.w):
+                if cells[y][x] != 0 and any(self._floor(x + dx, y + dy) for dx, dy in NAV[:4]):
+                    self.targets.append((x, y))
+
+    def _floor(self, x, y):
+        return 0 <= x < self.w and 0 <= y < self.h and self.cells[y][x] == 0
+
+    def _path_to(self, src, target, interesting):
+        # BFS over floor from src to any floor cell adjacent to target
+        prev = {src: None}
+        q = deque([src])
+        goal = None
+        while q:
+            c = q.popleft()
+            for k, (dx, dy) in enumerate(NAV[:4]):
+                if (c[0] + dx, c[1] + dy) == target:
+                    goal = (c, k)
+                    q.clear()
+                    break
+            else:
+                for k, (dx, dy) in enumerate(NAV[:4]):
+                    n = (c[0] + dx, c[1] + dy)
+                    if self._floor(*n) and n not in prev:
+                        prev[n] = (c, k)
+                        q.append(n)
+        if goal is None:
+            return None
+        c, last = goal
+        acts = [last]
+        while prev[c] is not None:
+            c, k = prev[c]
+            acts.append(k)
+        acts.reverse()
+        return acts
+
+    def act(self, env, ai):
+        if self.rng.random() < self.eps:
+            return self.rng.randrange(5)
+        if not self.plan[ai]:
+            a = env.sim_agents[ai]
+            # bias towards cells holding items / cutboards / delivery
+            hot = [tuple(o.location) for o in H.world_objects(env) if not o.is_held]
+            hot += [(x, y) for (x, y) in self.targets if self.cells[y][x] in (2, 3)]
+            pool = hot if (hot and self.rng.random() < 0.7) else self.targets
+            for _ in range(8):
+                t = pool[self.rng.randrange(len(pool))]
+                p = self._path_to(tuple(a.location), t, hot)
+                if p is not None:
+                    self.plan[ai] = deque(p)
+                    break
+            if not self.plan[ai]:
+                return self.rng.randrange(5)
+        return self.plan[ai].popleft()
+
+
+def run_base(level, A, T, tapes, ego_config=None, partner_config=None):
+    """tapes: list of (kind, spec).  Returns dict of arrays + static json."""
+    arg = H.make_arglist(level, A, T, ego_config=ego_config, partner_config=partner_config)
+    env = H.base_env(arg)
+    static = H.static_tables(env)
+    static.update(level=level, num_agents=A, max_num_timesteps=T,
+                  ego_config=arg.ego_config, partner_config=arg.partner_config,
+                  hashseed=os.environ.get("PYTHONHASHSEED", "unset"))
+    S = len(env.all_subtasks)
+    rec = {k: [] for k in ("actions", "items", "order", "agents", "nobj", "t", "reward",
+                           "done", "completed", "goal_count", "shaping", "reset_before",
+                           "tape_id")}
+    names = [a.name for a in env.sim_agents]
+
+    def fresh():
+        with H.quiet():
+            env.reset()
+        return H.base_items(env)
+
+    for tape_id, (kind, spec) in enumerate(tapes):
+        items = fresh()
+        need_reset_flag = 1
+        if kind == "script":
+            steps = len(spec)
+            rng = None
+        else:
+            steps, seed = spec
+            rng = random.Random(seed)
+        pol = Purposeful(static["cells"], A, rng) if kind == "purpose" else None
+        for k in range(steps):
+            if kind == "script":
+                acts = list(spec[k])
+                acts += [4] * (A - len(acts))
+            elif kind == "rand5":
+                acts = [rng.randrange(5) for _ in range(A)]
+            elif kind == "rand4":
+                acts = [rng.randrange(4) for _ in range(A)]
+            elif kind == "purpose":
+                acts = [pol.act(env, ai) for ai in range(A)]
+            else:
+                raise ValueError(kind)
+            with H.quiet():
+                r, d, info = env.step({n: NAV[a] for n, a in zip(names, acts)})
+            rows, order, agents, nobj = H.snapshot(env, items)
+            rec["actions"].append(acts)
+            rec["items"].append(rows)
+            rec["order"].append(order)
+            rec["agents"].append(agents)
+            rec["nobj"].append(nobj)
+            rec["t"].append(env.t)
+            rec["reward"].append(int(r))
+            rec["done"].append(1 if d else 0)
+            rec["completed"].append(list(env.completed_subtasks))
+            rec["goal_count"].append(list(env.goal_objects_count))
+            rec["shaping"].append([H.f64_bits(info["agent_0_reward_shaping"]),
+                                   H.f64_bits(info["agent_1_reward_shaping"])])
+            rec["reset_before"].append(need_reset_flag)
+            rec["tape_id"].append(tape_id)
+            need_reset_flag = 0
+            if d:
+                items = fresh()
+                need_reset_flag = 1
+                if pol is not None:
+                    pol.plan = [deque() for _ in range(A)]
+    out = {
+        "static_json": np.array(json.dumps(static)),
+        "actions": np.array(rec["actions"], dtype=np.int8),
+        "items": np.array(rec["items"], dtype=np.int8),
+        "order": np.array(rec["order"], dtype=np.int8),
+        "agents": np.array(rec["agents"], dtype=np.int8),
+        "nobj": np.array(rec["nobj"], dtype=np.int8),
+        "t": np.array(rec["t"], dtype=np.int32),
+        "reward": np.array(rec["reward"], dtype=np.int32),
+        "done": np.array(rec["done"], dtype=np.int8),
+        "completed": np.array(rec["completed"], dtype=np.int8).reshape(-1, S),
+        "goal_count": np.array(rec["goal_count"], dtype=np.int8).reshape(-1, S),
+        "shaping_bits": np.array(rec["shaping"], dtype=np.uint64),
+        "reset_before": np.array(rec["reset_before"], dtype=np.int8),
+        "tape_id": np.array(rec["tape_id"], dtype=np.int16),
+    }
+    return out, int(np.sum(out["reward"])), int(np.sum(out["done"]))
+
+
+OBS_KEYS = ["timestep", "object_encodings_x", "object_encodings_y", "state_encodings",
+            "is_hidden", "completed_subtasks", "agent1_location", "agent2_location",
+            "agent_is_holding", "agent1_comm", "agent2_comm"]
+
+
+def flat_obs(o):
+    """11 fields -> (timestep f64 bits, int64 vector of everything else, dtype tags)."""
+    ts = H.f64_bits(float(o["timestep"][0]))
+    vec = []
+    tags = []
+    for k in OBS_KEYS[1:]:
+        a = np.asarray(o[k])
+        tags.append(str(a.dtype))
+        # comm vectors are float64 one-hots; every other field is integral
+        vec.extend(int(v) for v in a.reshape(-1))
+        assert all(float(v) == int(v) for v in a.reshape(-1)), (k, a)
+    return ts, vec, tags
+
+
+def run_wrapper(name, level, T, steps, seed, kind="purpose", ego_agent_idx=0, **cfg):
+    arg = H.make_arglist(level, 2, T, **cfg)
+    env = H.wrapper_env(arg, ego_agent_idx=ego_agent_idx)
+    base = env.base_env
+    static = H.static_tables(base)
+    C = arg.num_communication
+    static.update(level=level, num_agents=2, max_num_timesteps=T,
+                  ego_config=arg.ego_config, partner_config=arg.partner_config,
+                  num_communication=C, communication_on=arg.communication_on,
+                  ego_led=arg.ego_led, fow_radius=arg.fow_radius,
+                  ego_agent_idx=ego_agent_idx,
+                  hashseed=os.environ.get("PYTHONHASHSEED", "unset"))
+    rng = random.Random(seed)
+    pol = Purposeful(static["cells"], 2, rng, eps=0.15) if kind == "purpose" else None
+    rec = {k: [] for k in ("actions", "ts_bits", "obs", "rew_bits", "done", "reset_before")}
+    # the constructor already did multi_reset(); record the obs of a fresh multi_reset
+    with H.quiet():
+        o0, o1 = env.multi_reset()
+    t0, v0, tags = flat_obs(o0)
+    t1, v1, _ = flat_obs(o1)
+    reset_obs = {"ts_bits": [t0, t1], "obs": [v0, v1]}
+    need_reset_flag = 1
+    for k in range(steps):
+        if pol is not None:
+            mv = [pol.act(base, 0), pol.act(base, 1)]
+            mv = [m if m < 4 else rng.randrange(4) for m in mv]   # wrapper has no no-op index
+        else:
+            mv = [rng.randrange(4), rng.randrange(4)]
+        cm = [rng.randrange(C), rng.randrange(C)]
+        # multi_step(ego_action, alt_action): the ego drives sim agent `ego_agent_idx`
+        # (overcooked_env.py:253-262).  Tapes are stored as (ego, alt).
+        if ego_agent_idx == 0:
+            ego, alt = (mv[0], cm[0]), (mv[1], cm[1])
+        else:
+            ego, alt = (mv[1], cm[0]), (mv[0], cm[1])
+        with H.quiet():
+            (o0, o1), (r0, r1), d, _ = env.multi_step(ego, alt)
+        assert H.f64_bits(r0) == H.f64_bits(r1)
+        t0, v0, _ = flat_obs(o0)
+        t1, v1, _ = flat_obs(o1)
+        rec["actions"].append([ego[0], ego[1], alt[0], alt[1]])
+        rec["ts_bits"].append([t0, t1])
+        rec["obs"].append([v0, v1])
+        rec["rew_bits"].append(H.f64_bits(r0))
+        rec["done"].append(1 if d else 0)
+        rec["reset_before"].append(need_reset_flag)
+        need_reset_flag = 0
+        if d:
+            with H.quiet():
+                env.multi_reset()
+            need_reset_flag = 1
+            if pol is not None:
+                pol.plan = [deque(), deque()]
+    static["obs_dtypes"] = dict(zip(OBS_KEYS[1:], tags))
+    out = {
+        "static_json": np.array(json.dumps(static)),
+        "actions": np.array(rec["actions"], dtype=np.int8),
+        "ts_bits": np.array(rec["ts_bits"], dtype=np.uint64),
+        "obs": np.array(rec["obs"], dtype=np.int16),
+        "rew_bits": np.array(rec["rew_bits"], dtype=np.uint64),
+        "done": np.array(rec["done"], dtype=np.int8),
+        "reset_before": np.array(rec["reset_before"], dtype=np.int8),
+        "reset_ts_bits": np.array(reset_obs["ts_bits"], dtype=np.uint64),
+        "reset_obs": np.array(reset_obs["obs"], dtype=np.int16),
+    }
+    return out, int(np.sum(out["done"]))
+
+
+def main():
+    assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
+    summary = {}
+
+    base_jobs = [
+        # level, A, T, tapes
+        ("open-divider_tomato", 2, 100,
+         [("script", KAT1_TOMATO), ("rand5", (1500, 0)), ("rand4", (500, 10)), ("purpose", (2500, 20))]),
+        ("full-divider_salad", 2, 100,
+         [("script", KAT2_SALAD), ("rand5", (1500, 1)), ("purpose", (3000, 21))]),
+        ("partial-divider_tl", 3, 100,
+         [("rand5", (1500, 2)), ("rand4", (500, 12)), ("purpose", (3000, 22))]),
+        ("open-divider_salad", 2, 150, [("rand5", (800, 3)), ("purpose", (2500, 23))]),
+        ("open-divider_tl", 2, 150, [("rand5", (800, 4)), ("purpose", (2500, 24))]),
+        ("open-divider_tl", 3, 100, [("rand5", (800, 6)), ("purpose", (2500, 26))]),
+        ("partial-divider_salad", 3, 100, [("rand5", (800, 5)), ("purpose", (2500, 25))]),
+        ("partial-divider_tomato", 4, 60, [("rand5", (600, 7)), ("purpose", (1500, 27))]),
+        ("full-divider_tl", 4, 80, [("purpose", (1500, 28))]),
+        ("full-divider_tomato", 2, 50, [("purpose", (1000, 29))]),
+    ]
+    for level, A, T, tapes in base_jobs:
+        out, sr, nd = run_base(level, A, T, tapes)
+        fn = "base_%s_a%d.npz" % (level, A)
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["t"])), "sum_reward": sr, "episodes": nd}
+        print(fn, summary[fn], flush=True)
+
+    # base env with an ALLERGIC ego / partner (agent.py:296-298)
+    out, sr, nd = run_base("open-divider_tomato", 2, 80, [("purpose", (1200, 40))],
+                           ego_config={"ALLERGIC": True})
+    np.savez_compressed(os.path.join(HERE, "base_allergic_ego.npz"), **out)
+    summary["base_allergic_ego.npz"] = {"steps": int(len(out["t"])), "sum_reward": sr, "episodes": nd}
+    out, sr, nd = run_base("partial-divider_tl", 3, 80, [("purpose", (1200, 41))],
+                           partner_config={"ALLERGIC": True})
+    np.savez_compressed(os.path.join(HERE, "base_allergic_partner.npz"), **out)
+    summary["base_allergic_partner.npz"] = {"steps": int(len(out["t"])), "sum_reward": sr, "episodes": nd}
+
+    wrap_jobs = [
+        # name, level, T, steps, seed, kwargs
+        ("tomato_r2", "open-divider_tomato", 100, 2500, 100, {}),
+        ("tomato_r0", "open-divider_tomato", 60, 800, 101, {"fow_radius": 0}),
+        ("tomato_r1", "open-divider_tomato", 60, 800, 102, {"fow_radius": 1}),
+        ("tomato_r1000", "open-divider_tomato", 60, 800, 103, {"fow_radius": 1000}),
+        ("salad_r2", "full-divider_salad", 100, 2500, 104, {}),
+        ("salad_open_c5", "open-divider_salad", 120, 2500, 105, {"num_communication": 5}),
+        ("tl_open_r3", "open-divider_tl", 120, 2500, 106, {"fow_radius": 3}),
+        ("tomato_commoff", "open-divider_tomato", 60, 600, 107, {"communication_on": False}),
+        ("tomato_egoled", "open-divider_tomato", 60, 600, 108, {"ego_led": True}),
+        ("tomato_blind_ego", "open-divider_tomato", 60, 800, 109, {"ego_config": {"BLIND": True}}),
+        ("tomato_blind_partner", "open-divider_tomato", 60, 800, 110, {"partner_config": {"BLIND": True}}),
+        ("tomato_allergic_ego", "open-divider_tomato", 60, 800, 111, {"ego_config": {"ALLERGIC": True}}),
+        ("tomato_allergic_partner", "open-divider_tomato", 60, 800, 112, {"partner_config": {"ALLERGIC": True}}),
+        ("tomato_pinned_ego", "open-divider_tomato", 60, 600, 113, {"ego_config": {"CAN_MOVE": False}}),
+        ("tomato_pinned_partner", "open-divider_tomato", 60, 600, 114, {"partner_config": {"CAN_MOVE": False}}),
+        ("salad_partial_rand", "partial-divider_salad", 80, 1000, 115, {"kind": "rand"}),
+        ("tomato_egoidx1", "open-divider_tomato", 60, 800, 116, {"ego_agent_idx": 1}),
+        ("tl_full_blind_allergic", "full-divider_tl", 60, 800, 117,
+         {"ego_config": {"BLIND": True}, "partner_config": {"ALLERGIC": True}, "ego_agent_idx": 1}),
+    ]
+    for name, level, T, steps, seed, kw in wrap_jobs:
+        kw = dict(kw)
+        kind = kw.pop("kind", "purpose")
+        eidx = kw.pop("ego_agent_idx", 0)
+        out, nd = run_wrapper(name, level, T, steps, seed, kind=kind, ego_agent_idx=eidx, **kw)
+        fn = "wrap_%s.npz" % name
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["done"])), "episodes": nd}
+        print(fn, summary[fn], flush=True)
+
+    with open(os.path.join(HERE, "SUMMARY.json"), "w") as f:
+        json.dump(summary, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
