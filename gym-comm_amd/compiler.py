@@ -1,0 +1,474 @@
+"""Level compiler: LevelSpec -> static tables -> the int32 "level blob" that the HIP
+library (and the test oracle) consume.
+
+Everything the reference recomputes on every ``reset()`` but that never changes for
+a given level is computed here once, on the host
+(gym_cooking/envs/overcooked_environment.py:180-206):
+
+  * the cell-type grid and item / agent start positions (``load_level`` :100-178);
+  * the subtask list (``run_recipes`` :452-459 -> recipe_planner/stripsworld.py:24-79
+    over the action sets of recipe_planner/recipe.py:5-97) together with the goal
+    object of every subtask (navigation_planner/utils.py:161-209);
+  * the path-distance table behind ``World.get_path_distance_between``
+    (utils/world.py:61-93,114-131), which reward shaping reads.
+
+Blob layout: see include/oc_hip.h (``OC_LV_*`` word offsets).
+"""
+from collections import deque
+from dataclasses import dataclass, field
+from itertools import combinations
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import levels as L
+
+MAGIC = 0x4F434C56          # 'OCLV'
+VERSION = 1
+HEADER_WORDS = 24
+MAX_AGENTS = 4
+MAX_ITEMS = 8
+MAX_SUBTASKS = 16
+MAX_CELLS = 128
+
+KIND_CHOP, KIND_MERGE, KIND_DELIVER = 0, 1, 2
+KIND_NAME = ["Chop", "Merge", "Deliver"]
+NAV_ACTIONS = [(0, 1), (0, -1), (-1, 0), (1, 0)]      # utils/world.py:16
+
+
+# --------------------------------------------------------------------------
+# recipes -> subtasks (own restatement of the STRIPS planner's result)
+# --------------------------------------------------------------------------
+RECIPE_INGREDIENTS = {          # recipe_planner/recipe.py:68-97
+    "SimpleTomato": ["Tomato"],
+    "SimpleLettuce": ["Lettuce"],
+    "Salad": ["Tomato", "Lettuce"],
+    "OnionSalad": ["Tomato", "Lettuce", "Onion"],
+}
+
+
+def _join(names):
+    return "-".join(sorted(names))
+
+
+class _Action:
+    __slots__ = ("kind", "args", "pre", "post")
+
+    def __init__(self, kind, args, pre, post):
+        self.kind, self.args, self.pre, self.post = kind, tuple(args), list(pre), list(post)
+
+    @property
+    def key(self):
+        return (self.kind, self.args)
+
+    def __repr__(self):
+        return "%s(%s)" % (self.kind, ", ".join(self.args))
+
+
+def _merge_action(a, b, pre=None):
+    # recipe_planner/utils.py:131-141: default pre = [Chopped(a), Merged(b)]
+    if pre is None:
+        pre = ["Chopped(%s)" % a, "Merged(%s)" % b]
+    post = ["Merged(%s)" % _join(a.split("-") + b.split("-"))]
+    return _Action("Merge", (a, b), pre, post)
+
+
+def recipe_actions(recipe_name: str) -> Tuple[Dict[tuple, _Action], str]:
+    """Action set of one recipe and its goal predicate (recipe.py:5-66).
+
+    Actions hash/compare on (name, args) only (recipe_planner/utils.py:83-89), so a
+    second action with the same name and args never replaces the first."""
+    if recipe_name not in RECIPE_INGREDIENTS:
+        raise ValueError("unknown recipe class %r" % recipe_name)
+    acts: Dict[tuple, _Action] = {}
+
+    def add(a):
+        acts.setdefault(a.key, a)
+
+    def get(x):
+        return _Action("Get", (x,), ["None"], ["Fresh(%s)" % x, "None"])
+
+    add(get("Plate"))
+    names = []
+    for ing in RECIPE_INGREDIENTS[recipe_name]:
+        names.append(ing)
+        add(get(ing))
+        add(_Action("Chop", (ing,), ["Fresh(%s)" % ing], ["Chopped(%s)" % ing]))
+        add(_merge_action(ing, "Plate", ["Chopped(%s)" % ing, "Fresh(Plate)"]))
+    names = sorted(names)
+    full_plate = _join(names + ["Plate"])
+    add(_Action("Deliver", (full_plate,), ["Merged(%s)" % full_plate],
+                ["Delivered(%s)" % full_plate]))
+    for i in range(2, len(names) + 1):
+        for combo in combinations(names, i):
+            cj = _join(combo)
+            add(_merge_action(cj, "Plate", ["Merged(%s)" % cj, "Fresh(Plate)"]))
+            for item in combo:
+                rem = [c for c in combo if c != item]
+                rem_str = _join(rem)
+                plate_str = _join([item, "Plate"])
+                rem_plate_str = _join(rem + ["Plate"])
+                if len(rem) == 1:
+                    add(_merge_action(item, rem_str,
+                                      ["Chopped(%s)" % item, "Chopped(%s)" % rem_str]))
+                    add(_merge_action(rem_str, plate_str))
+                    add(_merge_action(item, rem_plate_str))
+                else:
+                    add(_merge_action(item, rem_str))
+                    add(_merge_action(plate_str, rem_str,
+                                      ["Merged(%s)" % plate_str, "Merged(%s)" % rem_str]))
+                    add(_merge_action(item, rem_plate_str))
+    return acts, "Delivered(%s)" % full_plate
+
+
+def plan_subtasks(recipe_name: str, item_types: Sequence[int], max_path_length: int = 14):
+    """All actions that lie on some shortest plan for the recipe
+    (stripsworld.py:24-79): breadth-first search over predicate multisets from the
+    initial state (one ``Fresh(X)`` per world object that contains X, :19-22) until a
+    state with the recipe's ``Delivered`` predicate appears, then the union of the
+    edge labels over all shortest paths to it.
+
+    Two actions with the same effect label the same edge; networkx keeps whichever
+    was added last, which in the reference depends on ``set`` iteration order
+    (PYTHONHASHSEED).  We keep the one whose args sort last -- an arbitrary but
+    fixed choice; both have the same goal object."""
+    acts, goal = recipe_actions(recipe_name)
+    init = ["None"] + ["Fresh(%s)" % L.TYPE_NAME[t] for t in item_types]
+    start = tuple(sorted(init))
+    depth = {start: 0}
+    edges: Dict[Tuple[tuple, tuple], _Action] = {}
+    frontier = [start]
+    goal_state = None
+    for d in range(max_path_length):
+        nxt = []
+        for st in frontier:
+            for a in acts.values():
+                pool = list(st)
+                ok = True
+                for p in a.pre:
+                    if p in pool:
+                        pool.remove(p)
+                    else:
+                        ok = False
+                        break
+                if not ok:
+                    continue
+                ns = tuple(sorted(pool + a.post))
+                if ns not in depth:
+                    depth[ns] = d + 1
+                    nxt.append(ns)
+                if depth[ns] == d + 1:
+                    old = edges.get((st, ns))
+                    if old is None or a.args > old.args:
+                        edges[(st, ns)] = a
+                    if goal in ns and goal_state is None:
+                        goal_state = ns
+        if goal_state is not None:
+            break
+        frontier = nxt
+    if goal_state is None:
+        # stripsworld.py:53-56 prints and sys.exit(0)s here
+        raise RuntimeError("goal state could not be found, try increasing max_num_subtasks")
+    # backward sweep: edges (u,v) with depth[v]==depth[u]+1 and v on a shortest path
+    on_path = {goal_state}
+    used = {}
+    by_target: Dict[tuple, List[tuple]] = {}
+    for (u, v) in edges:
+        by_target.setdefault(v, []).append(u)
+    q = deque([goal_state])
+    while q:
+        v = q.popleft()
+        for u in by_target.get(v, []):
+            if depth[u] + 1 == depth[v]:
+                used[edges[(u, v)].key] = edges[(u, v)]
+                if u not in on_path:
+                    on_path.add(u)
+                    q.append(u)
+    return list(used.values())
+
+
+@dataclass
+class Subtask:
+    kind: int                     # KIND_*
+    args: Tuple[str, ...]
+    goal_types: Tuple[int, ...]   # sorted type ids of the goal object's contents
+    food: int = -1                # Chop only: the food type
+
+    @property
+    def name(self):
+        return "%s(%s)" % (KIND_NAME[self.kind], ", ".join(self.args))
+
+    @property
+    def goal_sig(self):
+        """Per-type content counts packed in nibbles (T | L<<4 | O<<8 | P<<12)."""
+        s = 0
+        for t in self.goal_types:
+            s += 1 << (4 * t)
+        return s
+
+
+def _subtask_from_action(a: _Action) -> Subtask:
+    """Goal object per subtask (navigation_planner/utils.py:161-209): Chop(X) ->
+    chopped X alone; Merge(a, b) -> all names of a and b, foods chopped;
+    Deliver(X) -> names of X, foods chopped."""
+    tid = {n: i for i, n in enumerate(L.TYPE_NAME)}
+    if a.kind == "Chop":
+        return Subtask(KIND_CHOP, a.args, (tid[a.args[0]],), food=tid[a.args[0]])
+    if a.kind == "Merge":
+        names = a.args[0].split("-") + a.args[1].split("-")
+        return Subtask(KIND_MERGE, a.args, tuple(sorted(tid[n] for n in names)))
+    if a.kind == "Deliver":
+        return Subtask(KIND_DELIVER, a.args, tuple(sorted(tid[n] for n in a.args[0].split("-"))))
+    raise ValueError("unexpected subtask %r" % (a,))
+
+
+_KIND_RANK = {"Chop": 0, "Merge": 1, "Deliver": 2}
+
+
+def canonical_subtasks(recipes: Sequence[str], item_types: Sequence[int],
+                       max_path_length: int = 14) -> List[Subtask]:
+    """Subtasks of all recipes, flattened recipe by recipe
+    (overcooked_environment.py:456-457).  Within a recipe the reference's order is
+    ``set`` iteration order, i.e. it changes with PYTHONHASHSEED; ours is Chop <
+    Merge < Deliver, then by args."""
+    out = []
+    for r in recipes:
+        acts = plan_subtasks(r, item_types, max_path_length)
+        acts.sort(key=lambda a: (_KIND_RANK[a.kind], a.args))
+        out.extend(_subtask_from_action(a) for a in acts)
+    return out
+
+
+def order_subtasks(subtasks: List[Subtask], order) -> List[Subtask]:
+    """Re-order to an explicit order: a permutation of indices, or a list of
+    ``[kind_name, [args...]]`` / ``"Kind(a, b)"`` entries (e.g. the order a golden
+    fixture was recorded with).  Merge entries match on the goal object, so
+    ``Merge(Tomato, Lettuce)`` and ``Merge(Lettuce, Tomato)`` are the same."""
+    if order is None:
+        return subtasks
+    order = list(order)
+    if all(isinstance(o, (int, np.integer)) for o in order):
+        if sorted(order) != list(range(len(subtasks))):
+            raise ValueError("subtask_order is not a permutation")
+        return [subtasks[i] for i in order]
+    pool = list(subtasks)
+    out = []
+    tid = {n: i for i, n in enumerate(L.TYPE_NAME)}
+    for o in order:
+        if isinstance(o, str):
+            kind, rest = o.split("(", 1)
+            args = [a.strip() for a in rest.rstrip(")").split(",")]
+        else:
+            kind, args = o[0], list(o[1])
+        k = _KIND_RANK[kind]
+        names = [n for a in args for n in a.split("-")]
+        goal = tuple(sorted(tid[n] for n in names))
+        hit = None
+        for st in pool:
+            if st.kind == k and st.goal_types == goal and (k != KIND_MERGE or tuple(args) == st.args):
+                hit = st
+                break
+        if hit is None:
+            for st in pool:
+                if st.kind == k and st.goal_types == goal and k == KIND_MERGE and \
+                        sorted(args) == sorted(st.args):
+                    hit = st
+                    break
+        if hit is None:
+            raise ValueError("subtask %r not produced by the planner (have %s)"
+                             % (o, [s.name for s in pool]))
+        pool.remove(hit)
+        out.append(Subtask(hit.kind, tuple(args), hit.goal_types, hit.food))
+    if pool:
+        raise ValueError("subtask_order misses %s" % [s.name for s in pool])
+    return out
+
+
+# --------------------------------------------------------------------------
+# path-distance table
+# --------------------------------------------------------------------------
+def distance_table(cells: List[List[int]]) -> np.ndarray:
+    """D[a][b] = ``World.get_path_distance_between(a, b)`` (utils/world.py:114-131)
+    for every ordered pair of cells, a and b as ``y*W + x``.
+
+    The reachability graph (world.py:61-93) has one node per Floor cell and one node
+    per (non-Floor cell, direction whose in-bounds-clamped neighbour is Floor);
+    edges join Floor neighbours and each (cell, direction) node to that Floor
+    neighbour.  Hence: D = MAX_PATH if a is not Floor (no source node, the lookup
+    raises and is skipped); the Floor-to-Floor hop count if b is Floor; otherwise
+    1 + the smallest hop count to a Floor 4-neighbour of b; MAX_PATH when
+    unreachable.  MAX_PATH = perimeter + 1 (:117)."""
+    h, w = len(cells), len(cells[0])
+    max_path = 2 * (w + h) + 1
+    n = w * h
+    D = np.full((n, n), max_path, dtype=np.int32)
+
+    def floor(x, y):
+        return 0 <= x < w and 0 <= y < h and cells[y][x] == L.FLOOR
+
+    for sy in range(h):
+        for sx in range(w):
+            if not floor(sx, sy):
+                continue
+            hop = {(sx, sy): 0}
+            q = deque([(sx, sy)])
+            while q:
+                cx, cy = q.popleft()
+                for dx, dy in NAV_ACTIONS:
+                    nx_, ny_ = cx + dx, cy + dy
+                    if floor(nx_, ny_) and (nx_, ny_) not in hop:
+                        hop[(nx_, ny_)] = hop[(cx, cy)] + 1
+                        q.append((nx_, ny_))
+            a = sy * w + sx
+            for by in range(h):
+                for bx in range(w):
+                    if floor(bx, by):
+                        d = hop.get((bx, by))
+                    else:
+                        best = None
+                        for dx, dy in NAV_ACTIONS:
+                            # world.py:75 clamps the neighbour in-bounds; a clamped
+                            # neighbour is the cell itself, which is not Floor
+                            nb = (bx + dx, by + dy)
+                            if floor(*nb) and nb in hop:
+                                c = hop[nb] + 1
+                                best = c if best is None or c < best else best
+                        d = best
+                    if d is not None and d < max_path:
+                        D[a, by * w + bx] = d
+    return D
+
+
+# --------------------------------------------------------------------------
+# compiled level
+# --------------------------------------------------------------------------
+@dataclass
+class CompiledLevel:
+    name: str
+    width: int
+    height: int
+    num_agents: int
+    max_num_timesteps: int
+    cells: np.ndarray                 # [H][W] int32
+    dist: np.ndarray                  # [HW][HW] int32
+    agents: List[Tuple[int, int]]
+    items: List[Tuple[int, int, int]]  # (type, x, y) in world.objects iteration order
+    subtasks: List[Subtask]
+    recipes: List[str]
+    pair_types: List[int]             # Plate + recipe[0] ingredients sorted by name
+    delivery: List[Tuple[int, int]]
+    allergic_mask: int
+    blob: np.ndarray = field(default=None, repr=False)
+
+    @property
+    def max_path(self):
+        return 2 * (self.width + self.height) + 1
+
+    @property
+    def num_items(self):
+        return len(self.items)
+
+    @property
+    def num_subtasks(self):
+        return len(self.subtasks)
+
+    @property
+    def hip_supported(self):
+        """The HIP path keys an object by the *set* of its content types, which is
+        exact while every food type occurs at most once in the level."""
+        foods = [t for t, _, _ in self.items if t != L.PLATE]
+        return len(foods) == len(set(foods))
+
+
+def world_order_items(spec: L.LevelSpec, placements=None) -> List[Tuple[int, int, int]]:
+    """Items in ``world.objects`` iteration order: dict keys are created the first
+    time a name is inserted (row-major map scan, then the scattered items in line
+    order, overcooked_environment.py:113-122,157-173) and each key's list keeps
+    insertion order, so items come grouped by type in first-appearance order."""
+    seq = list(spec.map_items)
+    if spec.scatter:
+        if placements is None:
+            raise ValueError("level %r scatters %r on random Counters; pass placements="
+                             % (spec.name, spec.scatter))
+        if len(placements) != len(spec.scatter):
+            raise ValueError("need %d placements" % len(spec.scatter))
+        for ch, (x, y) in zip(spec.scatter, placements):
+            if spec.cells[y][x] != L.COUNTER:
+                raise ValueError("placement (%d,%d) is not a Counter" % (x, y))
+            seq.append((L.TYPE_OF_CHAR[ch], x, y))
+        if len({(x, y) for _, x, y in seq}) != len(seq):
+            raise ValueError("two items on one Counter")
+    first = {}
+    for t, _, _ in seq:
+        first.setdefault(t, len(first))
+    return sorted(seq, key=lambda it: first[it[0]])     # stable: keeps scan order per type
+
+
+def compile_level(level, num_agents: int, max_num_timesteps: int = 100,
+                  max_num_subtasks: int = 14, ego_allergic: bool = False,
+                  partner_allergic: bool = False, subtask_order=None, placements=None,
+                  level_dir: Optional[str] = None) -> CompiledLevel:
+    spec = level if isinstance(level, L.LevelSpec) else L.load_level(level, level_dir)
+    if not (1 <= num_agents <= MAX_AGENTS):
+        raise ValueError("num_agents must be 1..%d" % MAX_AGENTS)
+    if num_agents > len(spec.agent_starts):
+        raise ValueError("level %r lists only %d agent starts" % (spec.name, len(spec.agent_starts)))
+    if spec.width * spec.height > MAX_CELLS or spec.width > 16 or spec.height > 16:
+        raise ValueError("level %r too large (%dx%d)" % (spec.name, spec.width, spec.height))
+    items = world_order_items(spec, placements)
+    if len(items) > MAX_ITEMS:
+        raise ValueError("too many items")
+    subtasks = canonical_subtasks(spec.recipes, [t for t, _, _ in items], max_num_subtasks)
+    subtasks = order_subtasks(subtasks, subtask_order)
+    if len(subtasks) > MAX_SUBTASKS:
+        raise ValueError("too many subtasks")
+    if not any(s.kind == KIND_DELIVER for s in subtasks):
+        raise AssertionError("no delivery subtask")        # overcooked_environment.py:251
+    cells = np.array(spec.cells, dtype=np.int32)
+    dist = distance_table(spec.cells)
+    delivery = [(x, y) for y in range(spec.height) for x in range(spec.width)
+                if spec.cells[y][x] == L.DELIVERY]
+    # pair term of reward shaping uses Plate + the FIRST recipe's ingredient names,
+    # sorted by name (overcooked_environment.py:319-321, recipe.py:28)
+    tid = {n: i for i, n in enumerate(L.TYPE_NAME)}
+    pair_types = [L.PLATE] + [tid[n] for n in sorted(RECIPE_INGREDIENTS[spec.recipes[0]])]
+    allergic = (1 if ego_allergic else 0)
+    if partner_allergic:
+        allergic |= ((1 << num_agents) - 1) & ~1
+    lv = CompiledLevel(
+        name=spec.name, width=spec.width, height=spec.height, num_agents=num_agents,
+        max_num_timesteps=int(max_num_timesteps), cells=cells, dist=dist,
+        agents=list(spec.agent_starts[:num_agents]), items=items, subtasks=subtasks,
+        recipes=list(spec.recipes), pair_types=pair_types, delivery=delivery,
+        allergic_mask=allergic)
+    lv.blob = build_blob(lv)
+    return lv
+
+
+def build_blob(lv: CompiledLevel) -> np.ndarray:
+    n = lv.width * lv.height
+    sec = {}
+    off = HEADER_WORDS
+    for key, size in (("cells", n), ("dist", n * n), ("agents", 2 * lv.num_agents),
+                      ("items", 3 * lv.num_items), ("subtasks", 4 * lv.num_subtasks),
+                      ("pair", len(lv.pair_types)), ("delivery", 2 * len(lv.delivery))):
+        sec[key] = off
+        off += size
+    b = np.zeros(off, dtype=np.int32)
+    b[0:16] = [MAGIC, VERSION, lv.width, lv.height, lv.num_agents, lv.num_items,
+               lv.num_subtasks, lv.max_num_timesteps, lv.max_path, lv.allergic_mask,
+               len(lv.pair_types), len(lv.delivery), 0, 0, 0, 0]
+    b[16:24] = [sec["cells"], sec["dist"], sec["agents"], sec["items"], sec["subtasks"],
+                sec["pair"], sec["delivery"], off]
+    b[sec["cells"]:sec["cells"] + n] = lv.cells.reshape(-1)
+    b[sec["dist"]:sec["dist"] + n * n] = lv.dist.reshape(-1)
+    b[sec["agents"]:sec["agents"] + 2 * lv.num_agents] = np.array(lv.agents).reshape(-1)
+    b[sec["items"]:sec["items"] + 3 * lv.num_items] = np.array(lv.items).reshape(-1)
+    st = []
+    for s in lv.subtasks:
+        st += [s.kind, s.goal_sig, s.food, len(s.goal_types)]
+    b[sec["subtasks"]:sec["subtasks"] + len(st)] = st
+    b[sec["pair"]:sec["pair"] + len(lv.pair_types)] = lv.pair_types
+    if lv.delivery:
+        b[sec["delivery"]:sec["delivery"] + 2 * len(lv.delivery)] = np.array(lv.delivery).reshape(-1)
+    return b

@@ -1,0 +1,74 @@
+/* Level blob: the static, per-level input shared by every entry point.
+ *
+ * A flat array of int32 words produced on the host by the level compiler
+ * (gym-comm_amd/compiler.py).  It holds everything the reference recomputes on
+ * every reset() although it never changes for a level
+ * (gym_cooking/envs/overcooked_environment.py:180-206): the cell grid, start
+ * positions, the subtask list with goal objects, and the path-distance table
+ * behind World.get_path_distance_between (gym_cooking/utils/world.py:114-131).
+ *
+ * Plain C, no dependencies: included by the HIP library and by the test oracle.
+ */
+#ifndef OC_LEVEL_H
+#define OC_LEVEL_H
+
+#include <stdint.h>
+
+#define OC_LV_MAGIC_VALUE 0x4F434C56 /* 'OCLV' */
+#define OC_LV_VERSION_VALUE 1
+
+/* header word indices */
+enum {
+  OC_LV_MAGIC = 0,
+  OC_LV_VERSION = 1,
+  OC_LV_W = 2,          /* world.width  */
+  OC_LV_H = 3,          /* world.height */
+  OC_LV_A = 4,          /* number of sim agents (2..4) */
+  OC_LV_M = 5,          /* number of movable base items (Tomato/Lettuce/Onion/Plate instances) */
+  OC_LV_S = 6,          /* number of subtasks */
+  OC_LV_T = 7,          /* arglist.max_num_timesteps (0 = no limit) */
+  OC_LV_MAX_PATH = 8,   /* world.perimeter + 1 */
+  OC_LV_ALLERGIC = 9,   /* bit a set: agent a has CONFIG["ALLERGIC"] */
+  OC_LV_NPAIR = 10,     /* length of the pair-term type list (Plate + recipe[0] ingredients) */
+  OC_LV_NDELIV = 11,    /* number of Delivery tiles */
+  /* 12..15 reserved */
+  OC_LV_OFF_CELLS = 16,    /* W*H words: cell type, index y*W+x */
+  OC_LV_OFF_DIST = 17,     /* (W*H)^2 words: D[a*W*H + b] */
+  OC_LV_OFF_AGENTS = 18,   /* A * {x, y} */
+  OC_LV_OFF_ITEMS = 19,    /* M * {type, x, y}, in world.objects iteration order */
+  OC_LV_OFF_SUBTASKS = 20, /* S * {kind, goal_sig, food_type, n_goal_contents} */
+  OC_LV_OFF_PAIR = 21,     /* NPAIR type ids */
+  OC_LV_OFF_DELIV = 22,    /* NDELIV * {x, y}, world order (row-major scan) */
+  OC_LV_TOTAL = 23,        /* total words */
+  OC_LV_HEADER_WORDS = 24
+};
+
+/* cell types (gym_cooking/utils/core.py:66-133) */
+enum { OC_FLOOR = 0, OC_COUNTER = 1, OC_CUTBOARD = 2, OC_DELIVERY = 3 };
+/* content types = observation channels (core.py:383-388) */
+enum { OC_TOMATO = 0, OC_LETTUCE = 1, OC_ONION = 2, OC_PLATE = 3, OC_NTYPES = 4 };
+/* subtask kinds (recipe_planner/utils.py:113-162) */
+enum { OC_CHOP = 0, OC_MERGE = 1, OC_DELIVER = 2 };
+/* action codes: 0..3 = World.NAV_ACTIONS in order (utils/world.py:16), 4 = (0,0) */
+enum { OC_ACT_DOWN = 0, OC_ACT_UP = 1, OC_ACT_LEFT = 2, OC_ACT_RIGHT = 3, OC_ACT_NOOP = 4 };
+
+#define OC_MAX_AGENTS 4
+#define OC_MAX_ITEMS 8
+#define OC_MAX_SUBTASKS 16
+#define OC_MAX_CELLS 128
+#define OC_MAX_DELIV 8
+#define OC_MAX_PAIR 4
+
+/* goal_sig: per-type content counts in nibbles: T | L<<4 | O<<8 | P<<12 */
+#define OC_SIG_OF_TYPE(t) (1 << (4 * (t)))
+
+/* per-env error flags (sticky until reset) for states where the reference itself
+ * raises; the step still completes with a defined result */
+enum {
+  OC_ERR_OOB = 1,    /* an agent's proposed cell is outside the map: the reference's
+                        get_gridsquare_at asserts (utils/world.py:310-315) */
+  OC_ERR_ALIAS = 2   /* World.remove() picked another agent's same-named object at the
+                        same cell (utils/world.py:239-247): only with >=3 agents overlapping */
+};
+
+#endif

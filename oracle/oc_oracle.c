@@ -1,0 +1,738 @@
+/* oc_oracle.c -- CPU restatement of the reference's Overcooked step/reset/obs path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker the HIP path is compared
+ * against; it is never linked into, imported by or called from the product
+ * package.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load it.
+ *
+ * Parity pin: the reference has no tests or fixtures for this path (SURVEY.md
+ * section 4), so this restatement is pinned by golden vectors recorded by running
+ * the reference itself in the build container (tests/golden/make_golden.py ->
+ * the .npz files under tests/golden; checked by tests/test_oracle_golden.py).
+ *
+ * It deliberately keeps the reference's data model -- a dict of object lists in
+ * insertion order, objects with an ordered contents list -- instead of the packed
+ * per-item words the HIP kernels use, so the two are independent derivations of
+ * the same semantics.  Every function cites the reference lines it follows
+ * (paths relative to the reference root).
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/oc_level.h"
+
+#define MAXOBJ 16
+#define MAXKEY 32
+#define MAXCONT OC_MAX_ITEMS
+
+typedef struct {
+  int type;  /* OC_TOMATO.. */
+  int state; /* Food.state_index: 0 fresh, 1 chopped; Plate: 0 */
+} Item;
+
+/* gym_cooking/utils/core.py:149-237 class Object */
+typedef struct {
+  int x, y;
+  int is_held;
+  int n;
+  int c[MAXCONT]; /* item ids, in contents-list order */
+} Obj;
+
+/* one entry of World.objects (a dict name -> list, utils/world.py:21), movable objects
+ * only; GridSquares live in the static cell table */
+typedef struct {
+  int sig; /* the name: counts of content types, nibble-packed */
+  int n;
+  int objs[MAXOBJ];
+} Key;
+
+typedef struct {
+  int kind, sig, food, ncont;
+} Sub;
+
+typedef struct {
+  /* static */
+  int W, H, A, M, S, T, max_path, allergic, npair, ndeliv;
+  const int32_t *cells, *dist, *agent0, *item0, *pair, *deliv;
+  Sub sub[OC_MAX_SUBTASKS];
+  int32_t *blob;
+  /* dynamic */
+  Item items[OC_MAX_ITEMS];
+  Obj objs[MAXOBJ];
+  int nobjs;
+  Key keys[MAXKEY];
+  int nkeys;
+  int ax[OC_MAX_AGENTS], ay[OC_MAX_AGENTS], ahold[OC_MAX_AGENTS]; /* obj id or -1 */
+  int adx[OC_MAX_AGENTS], ady[OC_MAX_AGENTS];
+  int t;
+  int completed[OC_MAX_SUBTASKS];
+  int goalcnt[OC_MAX_SUBTASKS];
+  int err;
+  int successful;
+} Env;
+
+static const int NAV_DX[5] = {0, 0, -1, 1, 0};
+static const int NAV_DY[5] = {1, -1, 0, 0, 0};
+
+/* ------------------------------------------------------------------ helpers */
+static int cell_at(const Env *e, int x, int y) { return e->cells[y * e->W + x]; }
+static int in_map(const Env *e, int x, int y) { return x >= 0 && x < e->W && y >= 0 && y < e->H; }
+static int D(const Env *e, int ax, int ay, int bx, int by) {
+  int n = e->W * e->H;
+  return e->dist[(ay * e->W + ax) * n + (by * e->W + bx)];
+}
+static int iabs(int v) { return v < 0 ? -v : v; }
+
+/* Object.update_names (core.py:182-186): name = sorted content names */
+static int obj_sig(const Env *e, const Obj *o) {
+  int s = 0;
+  for (int i = 0; i < o->n; i++) s += OC_SIG_OF_TYPE(e->items[o->c[i]].type);
+  return s;
+}
+
+/* world.insert (world.py:236-237) */
+static void world_insert(Env *e, int oid) {
+  int sig = obj_sig(e, &e->objs[oid]);
+  for (int k = 0; k < e->nkeys; k++)
+    if (e->keys[k].sig == sig) {
+      e->keys[k].objs[e->keys[k].n++] = oid;
+      return;
+    }
+  Key *nk = &e->keys[e->nkeys++];
+  nk->sig = sig;
+  nk->n = 1;
+  nk->objs[0] = oid;
+}
+
+/* world.remove (world.py:239-247): by NAME and LOCATION, last match wins.
+ * Returns the object id actually removed, -1 if the assert would fire. */
+static int world_remove(Env *e, int oid) {
+  const Obj *o = &e->objs[oid];
+  int sig = obj_sig(e, o);
+  for (int k = 0; k < e->nkeys; k++) {
+    Key *key = &e->keys[k];
+    if (key->sig != sig) continue;
+    int index = -1;
+    for (int i = 0; i < key->n; i++) {
+      const Obj *c = &e->objs[key->objs[i]];
+      if (c->x == o->x && c->y == o->y) index = i;
+    }
+    if (index < 0) return -1;
+    int removed = key->objs[index];
+    for (int i = index; i + 1 < key->n; i++) key->objs[i] = key->objs[i + 1];
+    key->n--;
+    return removed;
+  }
+  return -1;
+}
+
+/* iterate World.objects.values() flattened (world.py:249-253), movable objects only */
+static int world_list(const Env *e, int out[MAXOBJ * 2]) {
+  int n = 0;
+  for (int k = 0; k < e->nkeys; k++)
+    for (int i = 0; i < e->keys[k].n; i++) out[n++] = e->keys[k].objs[i];
+  return n;
+}
+
+/* world.is_occupied (world.py:217-222) */
+static int is_occupied(const Env *e, int x, int y) {
+  int lst[MAXOBJ * 2];
+  int n = world_list(e, lst);
+  for (int i = 0; i < n; i++) {
+    const Obj *o = &e->objs[lst[i]];
+    if (o->x == x && o->y == y && !o->is_held) return 1;
+  }
+  return 0;
+}
+
+/* world.get_object_at(location, None, find_held_objects=False) (world.py:293-308) */
+static int get_unheld_object_at(Env *e, int x, int y) {
+  int lst[MAXOBJ * 2];
+  int n = world_list(e, lst), found = -1, cnt = 0;
+  for (int i = 0; i < n; i++) {
+    const Obj *o = &e->objs[lst[i]];
+    if (o->x == x && o->y == y && !o->is_held) {
+      if (cnt == 0) found = lst[i];
+      cnt++;
+    }
+  }
+  if (cnt != 1) e->err |= OC_ERR_ALIAS; /* the reference asserts len(objs) == 1 */
+  return found;
+}
+
+/* Object.needs_chopped (core.py:191-193) + Food.needs_chopped (:302-303) */
+static int needs_chopped(const Env *e, const Obj *o) {
+  if (o->n > 1) return 0;
+  const Item *it = &e->items[o->c[0]];
+  return it->type != OC_PLATE && it->state == 0;
+}
+
+/* Object.is_deliverable (core.py:232-237) */
+static int is_deliverable(const Env *e, const Obj *o) {
+  for (int i = 0; i < o->n; i++) {
+    const Item *it = &e->items[o->c[i]];
+    if (!(it->type == OC_PLATE || it->state == 1)) return 0;
+  }
+  return o->n > 1;
+}
+
+/* mergeable (core.py:240-257): at most one Plate in the union, every Food done */
+static int mergeable(const Env *e, const Obj *a, const Obj *b) {
+  int plates = 0;
+  const Obj *two[2] = {a, b};
+  for (int k = 0; k < 2; k++)
+    for (int i = 0; i < two[k]->n; i++)
+      if (e->items[two[k]->c[i]].type == OC_PLATE) plates++;
+  if (plates > 1) return 0;
+  for (int k = 0; k < 2; k++)
+    for (int i = 0; i < two[k]->n; i++) {
+      const Item *it = &e->items[two[k]->c[i]];
+      if (it->type != OC_PLATE && it->state != 1) return 0;
+    }
+  return 1;
+}
+
+/* ------------------------------------------------------------------ reset */
+/* OvercookedEnvironment.reset / load_level (overcooked_environment.py:100-206):
+ * a fresh World; items inserted in world order; counters etc. are static. */
+static void env_reset(Env *e) {
+  e->nobjs = 0;
+  e->nkeys = 0;
+  for (int i = 0; i < e->M; i++) {
+    e->items[i].type = e->item0[3 * i];
+    e->items[i].state = 0;
+    Obj *o = &e->objs[e->nobjs];
+    o->x = e->item0[3 * i + 1];
+    o->y = e->item0[3 * i + 2];
+    o->is_held = 0;
+    o->n = 1;
+    o->c[0] = i;
+    world_insert(e, e->nobjs);
+    e->nobjs++;
+  }
+  for (int a = 0; a < e->A; a++) {
+    e->ax[a] = e->agent0[2 * a];
+    e->ay[a] = e->agent0[2 * a + 1];
+    e->ahold[a] = -1;
+    e->adx[a] = e->ady[a] = 0;
+  }
+  e->t = 0;
+  for (int s = 0; s < e->S; s++) e->completed[s] = e->goalcnt[s] = 0;
+  e->err = 0;
+  e->successful = 0;
+}
+
+/* ------------------------------------------------------------------ collisions */
+/* is_collision (overcooked_environment.py:543-576) */
+static void is_collision(Env *e, int i, int j, int exec_[2]) {
+  exec_[0] = exec_[1] = 1;
+  int nix = e->ax[i] + e->adx[i], niy = e->ay[i] + e->ady[i];
+  if (!in_map(e, nix, niy)) {
+    e->err |= OC_ERR_OOB; /* get_gridsquare_at asserts; treat as collidable */
+    nix = e->ax[i];
+    niy = e->ay[i];
+  } else if (cell_at(e, nix, niy) != OC_FLOOR) {
+    nix = e->ax[i];
+    niy = e->ay[i];
+  }
+  int njx = e->ax[j] + e->adx[j], njy = e->ay[j] + e->ady[j];
+  if (!in_map(e, njx, njy)) {
+    e->err |= OC_ERR_OOB;
+    njx = e->ax[j];
+    njy = e->ay[j];
+  } else if (cell_at(e, njx, njy) != OC_FLOOR) {
+    njx = e->ax[j];
+    njy = e->ay[j];
+  }
+  if (nix == njx && niy == njy) {
+    if (nix == e->ax[i] && niy == e->ay[i] && (e->adx[i] != 0 || e->ady[i] != 0))
+      exec_[1] = 0;
+    else if (njx == e->ax[j] && njy == e->ay[j] && (e->adx[j] != 0 || e->ady[j] != 0))
+      exec_[0] = 0;
+    else
+      exec_[0] = exec_[1] = 0;
+  } else if (e->ax[i] == njx && e->ay[i] == njy && e->ax[j] == nix && e->ay[j] == niy) {
+    exec_[0] = exec_[1] = 0;
+  }
+}
+
+/* check_collisions (:578-613): every unordered pair, on the ORIGINAL actions */
+static void check_collisions(Env *e) {
+  int execute[OC_MAX_AGENTS];
+  for (int a = 0; a < e->A; a++) execute[a] = 1;
+  for (int i = 0; i < e->A; i++)
+    for (int j = i + 1; j < e->A; j++) {
+      int ex[2];
+      is_collision(e, i, j, ex);
+      if (!ex[0]) execute[i] = 0;
+      if (!ex[1]) execute[j] = 0;
+    }
+  for (int a = 0; a < e->A; a++)
+    if (!execute[a]) e->adx[a] = e->ady[a] = 0;
+}
+
+/* ------------------------------------------------------------------ interact */
+/* SimAgent.move_to (utils/agent.py:311-314) */
+static void agent_move_to(Env *e, int a, int x, int y) {
+  e->ax[a] = x;
+  e->ay[a] = y;
+  if (e->ahold[a] >= 0) {
+    e->objs[e->ahold[a]].x = x;
+    e->objs[e->ahold[a]].y = y;
+  }
+}
+
+/* interact (utils/interact.py:4-75), arglist.play == False */
+static void interact(Env *e, int a) {
+  if (e->adx[a] == 0 && e->ady[a] == 0) return; /* :12 */
+  int tx = e->ax[a] + e->adx[a], ty = e->ay[a] + e->ady[a];
+  /* world.inbounds (world.py:317-320) */
+  if (tx < 0) tx = 0;
+  if (tx > e->W - 1) tx = e->W - 1;
+  if (ty < 0) ty = 0;
+  if (ty > e->H - 1) ty = e->H - 1;
+  int gs = cell_at(e, tx, ty);
+
+  if (gs == OC_FLOOR) { /* :19-20 */
+    agent_move_to(e, a, tx, ty);
+  } else if (e->ahold[a] >= 0) { /* :23 */
+    int hid = e->ahold[a];
+    Obj *held = &e->objs[hid];
+    if (gs == OC_DELIVERY) { /* :25-30 */
+      if (is_deliverable(e, held)) {
+        held->x = tx; /* Delivery.acquire (core.py:123-125) */
+        held->y = ty;
+        held->is_held = 0; /* agent.release (agent.py:307-309) */
+        e->ahold[a] = -1;
+      }
+    } else if (is_occupied(e, tx, ty)) { /* :33-46 */
+      int oid = get_unheld_object_at(e, tx, ty);
+      Obj *obj = &e->objs[oid];
+      if (mergeable(e, held, obj)) {
+        if (world_remove(e, oid) != oid) e->err |= OC_ERR_ALIAS;
+        if (world_remove(e, hid) != hid) e->err |= OC_ERR_ALIAS;
+        /* agent.acquire(obj) -> holding.merge(obj) (agent.py:305, core.py:210-218) */
+        for (int i = 0; i < obj->n; i++) held->c[held->n++] = obj->c[i];
+        world_insert(e, hid);
+      }
+    } else { /* :50-59 */
+      if (gs == OC_CUTBOARD && needs_chopped(e, held)) {
+        e->items[held->c[0]].state += 1; /* Object.chop -> Food.update_state */
+      } else {
+        held->x = tx; /* gs.acquire(obj) */
+        held->y = ty;
+        held->is_held = 0; /* agent.release() */
+        e->ahold[a] = -1;
+      }
+    }
+  } else { /* :62-75 */
+    if (is_occupied(e, tx, ty) && gs != OC_DELIVERY) {
+      int oid = get_unheld_object_at(e, tx, ty);
+      /* gs.release(); agent.acquire(obj): no-op for an ALLERGIC agent (agent.py:296-298) */
+      if (!((e->allergic >> a) & 1)) {
+        Obj *obj = &e->objs[oid];
+        e->ahold[a] = oid;
+        obj->is_held = 1;
+        obj->x = e->ax[a];
+        obj->y = e->ay[a];
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ goals */
+/* Object.__eq__ against the goal object of subtask s (core.py:164-169,
+ * navigation_planner/utils.py:161-209): same names, same length, every food chopped */
+static int matches_goal(const Env *e, const Obj *o, const Sub *s) {
+  if (obj_sig(e, o) != s->sig || o->n != s->ncont) return 0;
+  for (int i = 0; i < o->n; i++) {
+    const Item *it = &e->items[o->c[i]];
+    if (it->type != OC_PLATE && it->state != 1) return 0;
+  }
+  return 1;
+}
+
+/* world.get_all_object_locs(obj=goal) (world.py:278-291): distinct locations of the
+ * objects equal to the goal, held or not.  Returns count; first loc in (*x,*y). */
+static int goal_locs(const Env *e, const Sub *s, int *xs, int *ys) {
+  int lst[MAXOBJ * 2];
+  int n = world_list(e, lst), cnt = 0;
+  for (int i = 0; i < n; i++) {
+    const Obj *o = &e->objs[lst[i]];
+    if (!matches_goal(e, o, s)) continue;
+    int dup = 0;
+    for (int k = 0; k < cnt; k++)
+      if (xs[k] == o->x && ys[k] == o->y) dup = 1;
+    if (!dup) {
+      xs[cnt] = o->x;
+      ys[cnt] = o->y;
+      cnt++;
+    }
+  }
+  return cnt;
+}
+
+/* location of the fresh X alone, for Chop(X) (start_obj of get_subtask_obj) */
+static int fresh_loc(const Env *e, int food, int *x, int *y) {
+  int lst[MAXOBJ * 2];
+  int n = world_list(e, lst);
+  for (int i = 0; i < n; i++) {
+    const Obj *o = &e->objs[lst[i]];
+    if (o->n == 1 && e->items[o->c[0]].type == food && e->items[o->c[0]].state == 0) {
+      *x = o->x;
+      *y = o->y;
+      return 1;
+    }
+  }
+  return 0;
+}
+
+/* done (overcooked_environment.py:243-270) */
+static int env_done(Env *e) {
+  if (e->T && e->t >= e->T) {
+    e->successful = 0;
+    return 1;
+  }
+  for (int s = 0; s < e->S; s++) {
+    if (e->sub[s].kind != OC_DELIVER) continue;
+    int xs[MAXOBJ], ys[MAXOBJ];
+    int n = goal_locs(e, &e->sub[s], xs, ys), hit = 0;
+    for (int k = 0; k < n; k++)
+      if (xs[k] == e->deliv[0] && ys[k] == e->deliv[1]) hit = 1; /* first Delivery tile only (:259) */
+    if (!hit) {
+      e->successful = 0;
+      return 0;
+    }
+  }
+  e->successful = 1;
+  return 1;
+}
+
+/* subtask_reward + reward (:399-432) */
+static int env_reward(Env *e) {
+  int reward = 0;
+  for (int s = 0; s < e->S; s++) {
+    int r = 0;
+    int xs[MAXOBJ], ys[MAXOBJ];
+    int n = goal_locs(e, &e->sub[s], xs, ys);
+    if (e->sub[s].kind == OC_DELIVER) {
+      for (int k = 0; k < n; k++)
+        if (xs[k] == e->deliv[0] && ys[k] == e->deliv[1]) r = 3;
+    } else {
+      if (n > e->goalcnt[s]) r = 1;
+      e->goalcnt[s] = n;
+    }
+    reward += r;
+    if (r != 0) e->completed[s] = 1;
+  }
+  return reward;
+}
+
+/* calculate_reward_shaping (:272-397).  Every division is int / int in Python, i.e.
+ * one correctly rounded fp64 division; sums run left to right in fp64. */
+static double reward_shaping(const Env *e, int a) {
+  const int MAXP = e->max_path;
+  const int agx = e->ax[a], agy = e->ay[a];
+  double total = 0.0;
+  int total_is_zero = 1; /* Python `total_penalty == 0` */
+
+  /* Chop term (:278-304) */
+  int nchop = 0, mind = 0;
+  for (int s = 0; s < e->S; s++) {
+    if (e->sub[s].kind != OC_CHOP || e->completed[s]) continue;
+    int x = 0, y = 0;
+    if (!fresh_loc(e, e->sub[s].food, &x, &y)) continue; /* unreachable: IndexError in the reference */
+    int d = D(e, agx, agy, x, y);
+    if (nchop == 0 || d < mind) mind = d;
+    nchop++;
+  }
+  if (nchop > 0) {
+    total += (double)((mind + MAXP) + (nchop - 1) * 2 * MAXP) / (double)MAXP;
+    total_is_zero = (total == 0.0);
+  }
+
+  /* pair term (:319-363): Plate + recipes[0] ingredient names */
+  int lx[OC_MAX_PAIR][MAXOBJ], ly[OC_MAX_PAIR][MAXOBJ], ln[OC_MAX_PAIR];
+  for (int p = 0; p < e->npair; p++) ln[p] = 0;
+  {
+    int lst[MAXOBJ * 2];
+    int n = world_list(e, lst);
+    for (int i = 0; i < n; i++) {
+      const Obj *o = &e->objs[lst[i]];
+      for (int c = 0; c < o->n; c++)
+        for (int p = 0; p < e->npair; p++)
+          if (e->items[o->c[c]].type == e->pair[p]) {
+            lx[p][ln[p]] = o->x;
+            ly[p][ln[p]] = o->y;
+            ln[p]++;
+          }
+    }
+  }
+  int npairs = 0, minpair = 0;
+  for (int p = 0; p < e->npair; p++)
+    for (int q = p + 1; q < e->npair; q++) {
+      int val;
+      if (ln[p] > 0 && ln[q] > 0) {
+        int m = MAXP;
+        for (int i = 0; i < ln[p]; i++)
+          for (int j = 0; j < ln[q]; j++) {
+            int d = D(e, lx[p][i], ly[p][i], lx[q][j], ly[q][j]);
+            if (d < m) m = d;
+          }
+        if (m == 0) continue;
+        val = m;
+      } else {
+        val = MAXP;
+      }
+      if (npairs == 0 || val < minpair) minpair = val;
+      npairs++;
+    }
+  if (npairs > 0) {
+    if (total_is_zero)
+      total += (double)(minpair + (npairs - 1) * MAXP) / (double)MAXP;
+    else
+      total += (double)(npairs * MAXP) / (double)MAXP;
+  }
+
+  /* Deliver term (:370-395) */
+  for (int s = 0; s < e->S; s++) {
+    if (e->sub[s].kind != OC_DELIVER || e->completed[s]) continue;
+    int xs[MAXOBJ], ys[MAXOBJ];
+    int n = goal_locs(e, &e->sub[s], xs, ys);
+    if (n == 0) {
+      total += 2.0;
+    } else {
+      int d = D(e, agx, agy, xs[0], ys[0]) + iabs(agx - xs[0]) + iabs(agy - ys[0]);
+      if (d == 0) {
+        int best = 0;
+        for (int k = 0; k < e->ndeliv; k++) {
+          int dx = e->deliv[2 * k], dy = e->deliv[2 * k + 1];
+          int dd = D(e, agx, agy, dx, dy) + iabs(agx - dx) + iabs(agy - dy);
+          if (k == 0 || dd < best) best = dd;
+        }
+        total += (double)best / (double)MAXP;
+      } else {
+        total += (double)d / (double)MAXP + 1.0;
+      }
+    }
+  }
+  return total;
+}
+
+/* ------------------------------------------------------------------ public API */
+#define OC_EXPORT __attribute__((visibility("default")))
+
+OC_EXPORT void *oc_oracle_create(const int32_t *blob, int n_words) {
+  if (!blob || n_words < OC_LV_HEADER_WORDS || blob[OC_LV_MAGIC] != OC_LV_MAGIC_VALUE ||
+      blob[OC_LV_VERSION] != OC_LV_VERSION_VALUE || blob[OC_LV_TOTAL] != n_words)
+    return NULL;
+  Env *e = (Env *)calloc(1, sizeof(Env));
+  e->blob = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_words);
+  memcpy(e->blob, blob, sizeof(int32_t) * (size_t)n_words);
+  const int32_t *b = e->blob;
+  e->W = b[OC_LV_W]; e->H = b[OC_LV_H]; e->A = b[OC_LV_A]; e->M = b[OC_LV_M];
+  e->S = b[OC_LV_S]; e->T = b[OC_LV_T]; e->max_path = b[OC_LV_MAX_PATH];
+  e->allergic = b[OC_LV_ALLERGIC]; e->npair = b[OC_LV_NPAIR]; e->ndeliv = b[OC_LV_NDELIV];
+  e->cells = b + b[OC_LV_OFF_CELLS];
+  e->dist = b + b[OC_LV_OFF_DIST];
+  e->agent0 = b + b[OC_LV_OFF_AGENTS];
+  e->item0 = b + b[OC_LV_OFF_ITEMS];
+  e->pair = b + b[OC_LV_OFF_PAIR];
+  e->deliv = b + b[OC_LV_OFF_DELIV];
+  for (int s = 0; s < e->S; s++) {
+    const int32_t *p = b + b[OC_LV_OFF_SUBTASKS] + 4 * s;
+    e->sub[s].kind = p[0]; e->sub[s].sig = p[1]; e->sub[s].food = p[2]; e->sub[s].ncont = p[3];
+  }
+  env_reset(e);
+  return e;
+}
+
+OC_EXPORT void oc_oracle_destroy(void *h) {
+  Env *e = (Env *)h;
+  if (!e) return;
+  free(e->blob);
+  free(e);
+}
+
+OC_EXPORT void *oc_oracle_clone(const void *h) {
+  const Env *s = (const Env *)h;
+  Env *e = (Env *)malloc(sizeof(Env));
+  memcpy(e, s, sizeof(Env));
+  size_t nw = (size_t)s->blob[OC_LV_TOTAL];
+  e->blob = (int32_t *)malloc(sizeof(int32_t) * nw);
+  memcpy(e->blob, s->blob, sizeof(int32_t) * nw);
+  ptrdiff_t shift = e->blob - s->blob;
+  e->cells += shift; e->dist += shift; e->agent0 += shift; e->item0 += shift;
+  e->pair += shift; e->deliv += shift;
+  return e;
+}
+
+OC_EXPORT void oc_oracle_reset(void *h) { env_reset((Env *)h); }
+
+/* OvercookedEnvironment.step (overcooked_environment.py:211-241).
+ * actions: A codes (0..4).  shaping[2] = agent_0 / agent_1 reward shaping. */
+OC_EXPORT void oc_oracle_step(void *h, const int32_t *actions, int32_t *reward, int32_t *done,
+                              double *shaping) {
+  Env *e = (Env *)h;
+  e->t += 1;
+  for (int a = 0; a < e->A; a++) {
+    int c = actions[a];
+    if (c < 0 || c > 4) c = 4;
+    e->adx[a] = NAV_DX[c];
+    e->ady[a] = NAV_DY[c];
+  }
+  check_collisions(e);
+  for (int a = 0; a < e->A; a++) interact(e, a); /* execute_navigation (:615-618) */
+  int d = env_done(e);
+  int r = env_reward(e);
+  shaping[0] = reward_shaping(e, 0);
+  shaping[1] = reward_shaping(e, 1);
+  *reward = r;
+  *done = d;
+}
+
+OC_EXPORT int oc_oracle_successful(const void *h) { return ((const Env *)h)->successful; }
+OC_EXPORT int oc_oracle_error(const void *h) { return ((const Env *)h)->err; }
+
+/* Canonical snapshot, the format of tests/golden base fixtures:
+ *   items  [M][5] : x, y, state_index, group (smallest item id in its object), holder agent (-1)
+ *   order  [M]    : groups in world.objects iteration order, -1 padded
+ *   agents [A][3] : x, y, held group (-1)
+ *   misc   [2]    : t, number of objects in the world
+ *   completed[S], goalcnt[S] */
+OC_EXPORT void oc_oracle_snapshot(const void *h, int32_t *items, int32_t *order, int32_t *agents,
+                                  int32_t *misc, int32_t *completed, int32_t *goalcnt) {
+  const Env *e = (const Env *)h;
+  int lst[MAXOBJ * 2];
+  int n = world_list(e, lst);
+  int group_of[MAXOBJ];
+  for (int i = 0; i < MAXOBJ; i++) group_of[i] = -2;
+  for (int i = 0; i < e->M; i++) order[i] = -1;
+  for (int i = 0; i < e->M * 5; i++) items[i] = -9;
+  for (int i = 0; i < n; i++) {
+    const Obj *o = &e->objs[lst[i]];
+    int g = o->c[0];
+    for (int c = 1; c < o->n; c++)
+      if (o->c[c] < g) g = o->c[c];
+    group_of[lst[i]] = g;
+    if (i < e->M) order[i] = g;
+    int holder = -1;
+    for (int a = 0; a < e->A; a++)
+      if (e->ahold[a] == lst[i]) holder = a;
+    for (int c = 0; c < o->n; c++) {
+      int32_t *row = items + 5 * o->c[c];
+      row[0] = o->x; row[1] = o->y; row[2] = e->items[o->c[c]].state; row[3] = g; row[4] = holder;
+    }
+  }
+  for (int a = 0; a < e->A; a++) {
+    agents[3 * a] = e->ax[a];
+    agents[3 * a + 1] = e->ay[a];
+    agents[3 * a + 2] = e->ahold[a] >= 0 ? group_of[e->ahold[a]] : -1;
+  }
+  misc[0] = e->t;
+  misc[1] = n;
+  for (int s = 0; s < e->S; s++) {
+    completed[s] = e->completed[s];
+    goalcnt[s] = e->goalcnt[s];
+  }
+}
+
+/* OvercookedMultiEnv.get_observation2 (gym_comm/envs/overcooked_env.py:105-159) for
+ * viewer 0 or 1.  out layout (int32, F = 22 + S + 2C entries):
+ *   x[4] y[4] state[4] hidden[4] completed[S] agent1_location[2] agent2_location[2]
+ *   agent_is_holding[2] agent1_comm[C] agent2_comm[C]
+ * comm[k] = index of the one-hot bit of per_agent_communications[k], -1 = all zeros.
+ * timestep = t / max_num_timesteps in fp64. */
+OC_EXPORT void oc_oracle_obs(const void *h, int viewer, int radius, int viewer_blind, int ego_blind,
+                             int C, const int32_t *comm, int32_t *out, double *timestep) {
+  const Env *e = (const Env *)h;
+  int dx[4] = {0, 0, 0, 0}, dy[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0}, hid[4] = {1, 1, 1, 1};
+  int vx = e->ax[viewer], vy = e->ay[viewer];
+  if (!viewer_blind) {
+    int lst[MAXOBJ * 2];
+    int n = world_list(e, lst);
+    for (int i = 0; i < n; i++) { /* last writer wins (:121-131) */
+      const Obj *o = &e->objs[lst[i]];
+      for (int c = 0; c < o->n; c++) {
+        const Item *it = &e->items[o->c[c]];
+        if (it->type != OC_PLATE) st[it->type] = it->state;
+        dx[it->type] = o->x - vx;
+        dy[it->type] = o->y - vy;
+      }
+    }
+    for (int k = 0; k < 4; k++) hid[k] = (iabs(dx[k]) + iabs(dy[k]) <= radius) ? 0 : 1;
+  }
+  int p = 0;
+  /* visible_distances: (0,0) when WITHIN the radius, the delta otherwise (:135; sic) */
+  for (int k = 0; k < 4; k++) out[p++] = (iabs(dx[k]) + iabs(dy[k]) <= radius) ? 0 : dx[k];
+  for (int k = 0; k < 4; k++) out[p++] = (iabs(dx[k]) + iabs(dy[k]) <= radius) ? 0 : dy[k];
+  for (int k = 0; k < 4; k++) out[p++] = st[k];
+  for (int k = 0; k < 4; k++) out[p++] = hid[k];
+  for (int s = 0; s < e->S; s++) out[p++] = e->completed[s];
+  out[p++] = viewer_blind ? 0 : e->ax[0];
+  out[p++] = viewer_blind ? 0 : e->ay[0];
+  out[p++] = viewer_blind ? 0 : e->ax[1];
+  out[p++] = viewer_blind ? 0 : e->ay[1];
+  out[p++] = ego_blind ? 0 : (e->ahold[viewer] >= 0 ? 1 : 0); /* :154, gated on the EGO's flag */
+  out[p++] = 0;
+  for (int k = 0; k < 2; k++)
+    for (int c = 0; c < C; c++) out[p++] = (comm[k] == c) ? 1 : 0;
+  *timestep = (double)e->t / (double)e->T;
+}
+
+/* ------------------------------------------------------------------ batch helpers
+ * (used by tests to drive many oracle envs with the same [row][n] tensors the HIP
+ * library takes, and by bench.py's cpu_baseline leg) */
+OC_EXPORT void oc_oracle_batch_step(void **envs, int64_t n0, int64_t n1, int64_t n_stride,
+                                    const int32_t *actions /*[A][n_stride]*/, int32_t *reward,
+                                    int32_t *done, double *shaping /*[2][n_stride]*/, int auto_reset) {
+  for (int64_t i = n0; i < n1; i++) {
+    Env *e = (Env *)envs[i];
+    int32_t act[OC_MAX_AGENTS];
+    for (int a = 0; a < e->A; a++) act[a] = actions[(int64_t)a * n_stride + i];
+    double sh[2];
+    oc_oracle_step(e, act, &reward[i], &done[i], sh);
+    shaping[i] = sh[0];
+    shaping[n_stride + i] = sh[1];
+    if (auto_reset && done[i]) env_reset(e);
+  }
+}
+
+/* gym_comm OvercookedMultiEnv.multi_step (overcooked_env.py:207-282) over a range of
+ * envs: actions [4][n] = ego move, ego comm, alt move, alt comm.  comm [2][n] is the
+ * persistent per_agent_communications state.  obs [2][F][n]. */
+OC_EXPORT void oc_oracle_batch_multi_step(void **envs, int64_t n0, int64_t n1, int64_t n_stride,
+                                          const int32_t *actions, int32_t *comm, int radius,
+                                          int blind_mask, int C, int communication_on, int ego_led,
+                                          int ego_agent_idx, int can_move_mask, int32_t *obs,
+                                          double *timestep, double *reward, int32_t *done,
+                                          int auto_reset) {
+  for (int64_t i = n0; i < n1; i++) {
+    Env *e = (Env *)envs[i];
+    int F = 22 + e->S + 2 * C;
+    int ego_mv = actions[0 * n_stride + i], ego_cm = actions[1 * n_stride + i];
+    int alt_mv = actions[2 * n_stride + i], alt_cm = actions[3 * n_stride + i];
+    comm[i] = communication_on ? ego_cm : -1;                          /* :227-246 */
+    comm[n_stride + i] = (communication_on && !ego_led) ? alt_cm : -1;
+    int32_t act[OC_MAX_AGENTS] = {4, 4, 4, 4};                         /* :250-262 */
+    int ego_slot = ego_agent_idx == 0 ? 0 : 1;
+    if (can_move_mask & 1) act[ego_slot] = ego_mv;
+    if (can_move_mask & 2) act[1 - ego_slot] = alt_mv;
+    int32_t r, d;
+    double sh[2];
+    oc_oracle_step(e, act, &r, &d, sh);
+    reward[i] = (double)r - sh[0] - sh[1];                             /* :282 */
+    done[i] = d;
+    if (auto_reset && d) env_reset(e);
+    int32_t tmp[64];
+    int32_t cm[2] = {comm[i], comm[n_stride + i]};
+    for (int v = 0; v < 2; v++) {
+      double ts;
+      oc_oracle_obs(e, v, radius, (blind_mask >> v) & 1, blind_mask & 1, C, cm, tmp, &ts);
+      for (int f = 0; f < F; f++) obs[((int64_t)v * F + f) * n_stride + i] = tmp[f];
+      timestep[i] = ts;
+    }
+  }
+}

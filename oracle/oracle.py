@@ -1,0 +1,216 @@
+"""ctypes binding of the CPU oracle (oracle/oc_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by ``__graft_entry__.smoke()`` and by
+``bench.py``'s ``cpu_baseline`` leg as the checker / reported baseline -- never by the
+product package.  The oracle restates the reference's step/reset/obs semantics and is
+pinned against golden vectors recorded from the reference itself
+(tests/golden/*.npz, tests/test_oracle_golden.py).
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboc_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "oc_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "oc_level.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    return _LIB_PATH
+
+
+_I32P = ctypes.POINTER(ctypes.c_int32)
+_F64P = ctypes.POINTER(ctypes.c_double)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.oc_oracle_create.restype = ctypes.c_void_p
+        L.oc_oracle_create.argtypes = [_I32P, ctypes.c_int]
+        L.oc_oracle_clone.restype = ctypes.c_void_p
+        L.oc_oracle_clone.argtypes = [ctypes.c_void_p]
+        L.oc_oracle_destroy.argtypes = [ctypes.c_void_p]
+        L.oc_oracle_reset.argtypes = [ctypes.c_void_p]
+        L.oc_oracle_step.argtypes = [ctypes.c_void_p, _I32P, _I32P, _I32P, _F64P]
+        L.oc_oracle_successful.argtypes = [ctypes.c_void_p]
+        L.oc_oracle_error.argtypes = [ctypes.c_void_p]
+        L.oc_oracle_snapshot.argtypes = [ctypes.c_void_p] + [_I32P] * 6
+        L.oc_oracle_obs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int, _I32P, _I32P, _F64P]
+        L.oc_oracle_batch_step.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64,
+                                           ctypes.c_int64, ctypes.c_int64, _I32P, _I32P, _I32P,
+                                           _F64P, ctypes.c_int]
+        L.oc_oracle_batch_multi_step.argtypes = (
+            [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+             _I32P, _I32P] + [ctypes.c_int] * 7 + [_I32P, _F64P, _F64P, _I32P, ctypes.c_int])
+        _lib = L
+    return _lib
+
+
+def _p32(a):
+    return a.ctypes.data_as(_I32P)
+
+
+def _p64(a):
+    return a.ctypes.data_as(_F64P)
+
+
+class OracleEnv:
+    """One environment instance of the oracle."""
+
+    def __init__(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.int32)
+        self.blob = blob
+        self.A, self.M, self.S = int(blob[4]), int(blob[5]), int(blob[6])
+        self._h = lib().oc_oracle_create(_p32(blob), int(blob.size))
+        if not self._h:
+            raise ValueError("bad level blob")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oc_oracle_destroy(self._h)
+            self._h = None
+
+    def reset(self):
+        lib().oc_oracle_reset(self._h)
+
+    def step(self, actions):
+        act = np.ascontiguousarray(actions, dtype=np.int32)
+        r = ctypes.c_int32()
+        d = ctypes.c_int32()
+        sh = np.zeros(2, dtype=np.float64)
+        lib().oc_oracle_step(self._h, _p32(act), ctypes.byref(r), ctypes.byref(d), _p64(sh))
+        return r.value, d.value, sh
+
+    @property
+    def error(self):
+        return lib().oc_oracle_error(self._h)
+
+    @property
+    def successful(self):
+        return lib().oc_oracle_successful(self._h)
+
+    def snapshot(self):
+        items = np.zeros((self.M, 5), np.int32)
+        order = np.zeros(self.M, np.int32)
+        agents = np.zeros((self.A, 3), np.int32)
+        misc = np.zeros(2, np.int32)
+        comp = np.zeros(self.S, np.int32)
+        gc = np.zeros(self.S, np.int32)
+        lib().oc_oracle_snapshot(self._h, _p32(items), _p32(order), _p32(agents), _p32(misc),
+                                 _p32(comp), _p32(gc))
+        return {"items": items, "order": order, "agents": agents, "t": int(misc[0]),
+                "nobj": int(misc[1]), "completed": comp, "goal_count": gc}
+
+    def obs(self, viewer, radius, viewer_blind, ego_blind, C, comm):
+        out = np.zeros(22 + self.S + 2 * C, np.int32)
+        ts = ctypes.c_double()
+        cm = np.ascontiguousarray(comm, dtype=np.int32)
+        lib().oc_oracle_obs(self._h, viewer, radius, int(viewer_blind), int(ego_blind), C,
+                            _p32(cm), _p32(out), ctypes.byref(ts))
+        return out, ts.value
+
+
+class OracleBatch:
+    """N oracle envs driven with the same [row][n] arrays the HIP library takes.
+    ``threads`` > 1 splits the env range over Python threads (ctypes drops the GIL)."""
+
+    def __init__(self, blob, n, threads=1):
+        self.blob = np.ascontiguousarray(blob, dtype=np.int32)
+        self.n = int(n)
+        self.A, self.M, self.S = int(blob[4]), int(blob[5]), int(blob[6])
+        self.threads = max(1, int(threads))
+        L = lib()
+        self._handles = (ctypes.c_void_p * self.n)()
+        first = L.oc_oracle_create(_p32(self.blob), int(self.blob.size))
+        if not first:
+            raise ValueError("bad level blob")
+        self._handles[0] = first
+        for i in range(1, self.n):
+            self._handles[i] = L.oc_oracle_clone(first)
+
+    def __del__(self):
+        L = lib()
+        for i in range(getattr(self, "n", 0)):
+            if self._handles[i]:
+                L.oc_oracle_destroy(self._handles[i])
+                self._handles[i] = None
+
+    def _ranges(self):
+        k = min(self.threads, self.n)
+        edges = [self.n * i // k for i in range(k + 1)]
+        return [(edges[i], edges[i + 1]) for i in range(k)]
+
+    def _run(self, fn):
+        rs = self._ranges()
+        if len(rs) == 1:
+            fn(*rs[0])
+            return
+        ts = [threading.Thread(target=fn, args=r) for r in rs]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    def reset(self):
+        for i in range(self.n):
+            lib().oc_oracle_reset(self._handles[i])
+
+    def step(self, actions, auto_reset=False):
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        assert actions.shape == (self.A, self.n)
+        reward = np.zeros(self.n, np.int32)
+        done = np.zeros(self.n, np.int32)
+        shaping = np.zeros((2, self.n), np.float64)
+        L = lib()
+        self._run(lambda a, b: L.oc_oracle_batch_step(
+            self._handles, a, b, self.n, _p32(actions), _p32(reward), _p32(done), _p64(shaping),
+            int(auto_reset)))
+        return reward, done, shaping
+
+    def multi_step(self, actions, comm, radius, blind_mask, C, communication_on=True,
+                   ego_led=False, ego_agent_idx=0, can_move_mask=3, auto_reset=False):
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        assert actions.shape == (4, self.n) and comm.shape == (2, self.n)
+        F = 22 + self.S + 2 * C
+        obs = np.zeros((2, F, self.n), np.int32)
+        ts = np.zeros(self.n, np.float64)
+        reward = np.zeros(self.n, np.float64)
+        done = np.zeros(self.n, np.int32)
+        L = lib()
+        self._run(lambda a, b: L.oc_oracle_batch_multi_step(
+            self._handles, a, b, self.n, _p32(actions), _p32(comm), radius, blind_mask, C,
+            int(communication_on), int(ego_led), ego_agent_idx, can_move_mask, _p32(obs),
+            _p64(ts), _p64(reward), _p32(done), int(auto_reset)))
+        return obs, ts, reward, done
+
+    def snapshot(self, i):
+        e = OracleEnv.__new__(OracleEnv)
+        e.A, e.M, e.S = self.A, self.M, self.S
+        e._h = self._handles[i]
+        try:
+            return e.snapshot()
+        finally:
+            e._h = None
+
+    def obs(self, i, viewer, radius, viewer_blind, ego_blind, C, comm):
+        e = OracleEnv.__new__(OracleEnv)
+        e.A, e.M, e.S = self.A, self.M, self.S
+        e._h = self._handles[i]
+        try:
+            return e.obs(viewer, radius, viewer_blind, ego_blind, C, comm)
+        finally:
+            e._h = None
