@@ -1,0 +1,74 @@
+"""ctypes loader for liboc_hip.so (include/oc_hip.h).
+
+There is no CPU fallback: if the library cannot be loaded, or a call fails, this
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never used here.)
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_I32P = ctypes.POINTER(ctypes.c_int32)
+_I64P = ctypes.POINTER(ctypes.c_int64)
+_F64P = ctypes.POINTER(ctypes.c_double)
+
+SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destroy",
+           "oc_state_words", "oc_obs_rows", "oc_reset", "oc_step", "oc_obs", "oc_multi_step"]
+
+
+class ObsCfg(ctypes.Structure):
+    _fields_ = [("fow_radius", ctypes.c_int32), ("blind_mask", ctypes.c_int32),
+                ("num_comm", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class WrapCfg(ctypes.Structure):
+    _fields_ = [("obs", ObsCfg), ("communication_on", ctypes.c_int32),
+                ("ego_led", ctypes.c_int32), ("ego_agent_idx", ctypes.c_int32),
+                ("can_move_mask", ctypes.c_int32)]
+
+
+class OcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(path=None):
+    """Load (once) and type the library.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("OC_HIP_LIB") or _build.LIB
+    if not os.path.exists(path):
+        raise OcError(
+            "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (there is no CPU fallback)" % path)
+    L = ctypes.CDLL(path)
+    vp = ctypes.c_void_p
+    L.oc_abi_version.restype = ctypes.c_int
+    L.oc_last_error.restype = ctypes.c_char_p
+    L.oc_level_create.argtypes = [_I32P, ctypes.c_int32, ctypes.POINTER(vp)]
+    L.oc_level_destroy.argtypes = [vp]
+    L.oc_state_words.argtypes = [vp]
+    L.oc_state_words.restype = ctypes.c_int32
+    L.oc_obs_rows.argtypes = [vp, ctypes.c_int32]
+    L.oc_obs_rows.restype = ctypes.c_int32
+    L.oc_reset.argtypes = [vp, vp, vp, ctypes.c_int64, vp]
+    L.oc_step.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, ctypes.c_int64, vp]
+    L.oc_obs.argtypes = [vp, vp, vp, ctypes.POINTER(ObsCfg), vp, vp, ctypes.c_int64, vp]
+    L.oc_multi_step.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
+                                ctypes.c_int32, vp, ctypes.c_int64, vp]
+    for f in ("oc_level_create", "oc_level_destroy", "oc_reset", "oc_step", "oc_obs",
+              "oc_multi_step"):
+        getattr(L, f).restype = ctypes.c_int
+    if L.oc_abi_version() != 1:
+        raise OcError("liboc_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().oc_last_error()
+        raise OcError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,173 @@
+"""BatchedOvercooked: N independent Overcooked envs of one level on one MI355X.
+
+Host side of the hot path: owns the PyTorch-ROCm tensors (env-major int32 SoA) and calls
+the hand-written HIP kernels of liboc_hip.so through the C ABI (include/oc_hip.h) with
+raw device pointers on torch's current stream.  No compute happens in Python or torch.
+
+Mirrors, batched:
+  gym_cooking.envs.OvercookedEnvironment.step/reset    (overcooked_environment.py:180-241)
+  gym_comm.envs.OvercookedMultiEnv.multi_step/multi_reset/get_observation2
+                                                       (overcooked_env.py:105-297)
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib, compiler
+from .state import unpack_state
+
+OBS_KEYS = ["object_encodings_x", "object_encodings_y", "state_encodings", "is_hidden",
+            "completed_subtasks", "agent1_location", "agent2_location", "agent_is_holding",
+            "agent1_comm", "agent2_comm"]
+
+
+def obs_layout(S, C):
+    """Row ranges of each observation key inside the [F] axis (F = 22 + S + 2C)."""
+    sizes = [4, 4, 4, 4, S, 2, 2, 2, C, C]
+    out, r = {}, 0
+    for k, s in zip(OBS_KEYS, sizes):
+        out[k] = (r, r + s)
+        r += s
+    return out
+
+
+class BatchedOvercooked:
+    def __init__(self, level, num_agents=2, num_envs=4096, max_num_timesteps=100,
+                 ego_config=None, partner_config=None, num_communication=2,
+                 communication_on=True, ego_led=False, fow_radius=2, ego_agent_idx=0,
+                 device="cuda", subtask_order=None, placements=None, level_dir=None,
+                 max_num_subtasks=14, auto_reset=True, track_metrics=True):
+        cfg = {"ALLERGIC": False, "BLIND": False, "CAN_MOVE": True}   # missing CAN_MOVE = True
+        self.ego_config = dict(cfg, **(ego_config or {}))
+        self.partner_config = dict(cfg, **(partner_config or {}))
+        if isinstance(level, compiler.CompiledLevel):
+            self.level = level
+        else:
+            self.level = compiler.compile_level(
+                level, num_agents, max_num_timesteps, max_num_subtasks,
+                ego_allergic=self.ego_config["ALLERGIC"],
+                partner_allergic=self.partner_config["ALLERGIC"],
+                subtask_order=subtask_order, placements=placements, level_dir=level_dir)
+        lv = self.level
+        if not lv.hip_supported:
+            raise ValueError("level %r repeats a food type; the HIP path does not support it" % lv.name)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.OcError("BatchedOvercooked needs a ROCm device (got %s); there is no CPU path"
+                               % self.device)
+        self.n = int(num_envs)
+        self.A, self.M, self.S = lv.num_agents, lv.num_items, lv.num_subtasks
+        self.C = int(num_communication)
+        self.auto_reset = bool(auto_reset)
+        self._L = _lib.load()
+        with torch.cuda.device(self.device):
+            h = ctypes.c_void_p()
+            blob = np.ascontiguousarray(lv.blob, dtype=np.int32)
+            _lib.check(self._L.oc_level_create(blob.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                               int(blob.size), ctypes.byref(h)), "oc_level_create")
+        self._h = h
+        self.W_state = self._L.oc_state_words(h)
+        self.F = self._L.oc_obs_rows(h, self.C)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        n = self.n
+        self.state = torch.zeros((self.W_state, n), **i32)
+        self.reward = torch.zeros(n, **i32)
+        self.done = torch.zeros(n, **i32)
+        self.shaping = torch.zeros((2, n), dtype=torch.float64, device=self.device)
+        self.comm = torch.zeros((2, n), **i32)                 # one-hot(0) (overcooked_env.py:89-91)
+        self.obs = torch.zeros((2, self.F, n), **i32)
+        self.timestep = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self.shaped_reward = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self.metrics = torch.zeros(8, dtype=torch.int64, device=self.device) if track_metrics else None
+        self._obs_cfg = _lib.ObsCfg(int(fow_radius),
+                                    (1 if self.ego_config["BLIND"] else 0) |
+                                    (2 if self.partner_config["BLIND"] else 0), self.C, 0)
+        self._wrap_cfg = _lib.WrapCfg(self._obs_cfg, int(bool(communication_on)), int(bool(ego_led)),
+                                      int(ego_agent_idx),
+                                      (1 if self.ego_config["CAN_MOVE"] else 0) |
+                                      (2 if self.partner_config["CAN_MOVE"] else 0))
+        self._layout = obs_layout(self.S, self.C)
+        self.reset()
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._L.oc_level_destroy(h)
+            self._h = None
+
+    # -- helpers ---------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+    def _check_tensor(self, t, shape, dtype, name):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s must be a torch tensor" % name)
+        if t.device != self.state.device or t.dtype != dtype or tuple(t.shape) != tuple(shape) \
+                or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s (got %s %s %s)"
+                             % (name, dtype, tuple(shape), self.state.device, t.dtype,
+                                tuple(t.shape), t.device))
+
+    # -- API -------------------------------------------------------------------
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        """Reset all envs, or those with mask[n] != 0 (int32 [n])."""
+        if mask is not None:
+            self._check_tensor(mask, (self.n,), torch.int32, "mask")
+        _lib.check(self._L.oc_reset(self._h, self._p(self.state), self._p(mask), self.n,
+                                    self._stream()), "oc_reset")
+
+    def step(self, actions: torch.Tensor, auto_reset: Optional[bool] = None):
+        """Base-env step.  actions: int32 [A][n] action codes 0..4 (4 = stay).
+        Returns (reward int32[n], done int32[n], shaping f64[2][n]) -- views of
+        pre-allocated tensors, overwritten by the next call."""
+        self._check_tensor(actions, (self.A, self.n), torch.int32, "actions")
+        ar = self.auto_reset if auto_reset is None else auto_reset
+        _lib.check(self._L.oc_step(self._h, self._p(self.state), self._p(actions),
+                                   self._p(self.reward), self._p(self.done), self._p(self.shaping),
+                                   int(ar), self._p(self.metrics), self.n, self._stream()), "oc_step")
+        return self.reward, self.done, self.shaping
+
+    def observe(self):
+        """Both viewers' observations of the current state.  Returns (obs int32 [2][F][n],
+        timestep f64 [n])."""
+        _lib.check(self._L.oc_obs(self._h, self._p(self.state), self._p(self.comm),
+                                  ctypes.byref(self._obs_cfg), self._p(self.obs),
+                                  self._p(self.timestep), self.n, self._stream()), "oc_obs")
+        return self.obs, self.timestep
+
+    def multi_step(self, actions: torch.Tensor, auto_reset: Optional[bool] = None):
+        """gym_comm wrapper step in one launch.  actions: int32 [4][n] = ego move (0..3),
+        ego comm, alt move, alt comm.  Returns (obs, timestep, shaped_reward f64[n], done)."""
+        self._check_tensor(actions, (4, self.n), torch.int32, "actions")
+        ar = self.auto_reset if auto_reset is None else auto_reset
+        _lib.check(self._L.oc_multi_step(
+            self._h, self._p(self.state), self._p(self.comm), self._p(actions),
+            ctypes.byref(self._wrap_cfg), self._p(self.obs), self._p(self.timestep),
+            self._p(self.shaped_reward), self._p(self.done), self._p(self.reward), int(ar),
+            self._p(self.metrics), self.n, self._stream()), "oc_multi_step")
+        return self.obs, self.timestep, self.shaped_reward, self.done
+
+    def obs_dict(self, viewer: int):
+        """The 11 observation keys of get_observation2 as tensor views: key -> [k][n]
+        (``.T`` gives the [n][k] batch a policy takes); 'timestep' is f64 [1][n]."""
+        d = {"timestep": self.timestep.unsqueeze(0)}
+        for k, (a, b) in self._layout.items():
+            d[k] = self.obs[viewer, a:b]
+        return d
+
+    def snapshot(self):
+        """Named fields of every env's state (host numpy), see state.unpack_state."""
+        return unpack_state(self.state.cpu().numpy(), self.A, self.M, self.S)
+
+    def read_metrics(self):
+        if self.metrics is None:
+            return None
+        m = self.metrics.cpu().tolist()
+        return {"env_steps": m[0], "episodes": m[1], "successes": m[2], "reward_sum": m[3],
+                "completed_subtasks_sum": m[4], "errors": m[5]}

@@ -1,0 +1,49 @@
+"""Build liboc_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU; the built library travels to the GPU box with the
+repo snapshot.  ``-ffp-contract=off``: reward shaping must reproduce CPython's fp64
+arithmetic bit for bit, so no fused multiply-adds may be formed.
+"""
+import os
+import shutil
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SOURCES = ["oc_kernels.hip"]
+LIB = os.path.join(CSRC, "liboc_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC=)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    deps = [os.path.join(CSRC, s) for s in SOURCES]
+    inc = os.path.join(CSRC, "..", "..", "include")
+    deps += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    return os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source into csrc/liboc_hip.so.  Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=" + ARCH] + FLAGS + list(extra_flags)
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

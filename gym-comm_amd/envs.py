@@ -1,0 +1,470 @@
+"""Single-env adapters with the reference's object API, backed by the HIP path.
+
+``OvercookedEnvironment``  mirrors gym_cooking.envs.OvercookedEnvironment
+                           (gym_cooking/envs/overcooked_environment.py:37-241)
+``OvercookedMultiEnv``     mirrors gym_comm.envs.OvercookedMultiEnv
+                           (gym_comm/envs/overcooked_env.py:15-297), including the
+                           pantheonrl SimultaneousEnv / MultiAgentEnv step/reset plumbing
+                           (pantheonrl/common/multiagentenv.py:172-243,383-409)
+
+so ``trainer.py`` / ``tester.py`` / ``episode_recorder.py`` keep working when the gym
+registry id ``OvercookedMultiCommEnv-v0`` points here.  Every step is
+one kernel launch on a 1-env batch; the batched API (batched.BatchedOvercooked, vec_env)
+is where the throughput is.
+
+Deviations, all of them deliberate and stated:
+  * a missing ``CAN_MOVE`` key in ego_config / partner_config means True (the reference
+    raises KeyError on the first step, overcooked_env.py:254; most of its own
+    spread/*.json configs lack the key);
+  * the path's many ``print`` calls are dropped;
+  * the subtask order is canonical (compiler.canonical_subtasks) unless
+    ``subtask_order=`` is given -- the reference's own order changes with PYTHONHASHSEED.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import levels as L
+from .batched import BatchedOvercooked, obs_layout
+from .compiler import KIND_NAME
+
+NAV_ACTIONS = [(0, 1), (0, -1), (-1, 0), (1, 0)]        # utils/world.py:16
+_CODE_OF = {(0, 1): 0, (0, -1): 1, (-1, 0): 2, (1, 0): 3, (0, 0): 4}
+
+
+def _arg(arglist, name, default=None):
+    if isinstance(arglist, dict):
+        return arglist.get(name, default)
+    return getattr(arglist, name, default)
+
+
+class _Content:
+    """A Food / Plate inside a held object (gym_cooking/utils/core.py:270-377)."""
+
+    def __init__(self, type_id, state_index):
+        self.name = L.TYPE_NAME[type_id]
+        self.state_index = state_index
+        if type_id == L.PLATE:
+            self.full_name = "Plate"
+        else:
+            self.full_name = ("Chopped" if state_index else "Fresh") + self.name
+
+    def __str__(self):
+        if self.name == "Plate":
+            return "p"
+        return "%d%s" % (self.state_index + 1, self.name[0].lower())
+
+
+class _Object:
+    """Read-only view of an Object (core.py:149-237)."""
+
+    def __init__(self, contents, location, is_held):
+        self.contents = contents
+        self.location = location
+        self.is_held = is_held
+        srt = sorted(contents, key=lambda c: c.name)
+        self.name = "-".join(c.name for c in srt)
+        self.full_name = "-".join(c.full_name for c in srt)
+
+    def __str__(self):
+        return "-".join(str(c) for c in sorted(self.contents, key=lambda c: c.name))
+
+
+class _SimAgent:
+    """Read-only view of a SimAgent (utils/agent.py:258-314)."""
+
+    def __init__(self, idx, config):
+        self.name = "agent-%d" % idx
+        self.location = (0, 0)
+        self.holding = None
+        self.action = (0, 0)
+        self.config = config
+
+    def __str__(self):
+        return self.name[-1]
+
+    def get_holding(self):
+        return "None" if self.holding is None else self.holding.full_name
+
+
+class OvercookedEnvironment:
+    """``OvercookedEnvironment(arglist)``: reset() -> None;
+    step({"agent-i": (dx, dy)}) -> (reward: int, done: bool, info: dict)."""
+
+    def __init__(self, arglist, device="cuda", subtask_order=None, placements=None,
+                 level_dir=None, _batch=None):
+        self.arglist = arglist
+        ego = dict(_arg(arglist, "ego_config", {}) or {})
+        partner = dict(_arg(arglist, "partner_config", {}) or {})
+        self._b = _batch or BatchedOvercooked(
+            _arg(arglist, "level"), num_agents=_arg(arglist, "num_agents"), num_envs=1,
+            max_num_timesteps=_arg(arglist, "max_num_timesteps", 100),
+            max_num_subtasks=_arg(arglist, "max_num_subtasks", 14),
+            ego_config=ego, partner_config=partner,
+            num_communication=_arg(arglist, "num_communication", 10),
+            communication_on=_arg(arglist, "communication_on", False),
+            ego_led=_arg(arglist, "ego_led", False), fow_radius=_arg(arglist, "fow_radius", 2),
+            device=device, subtask_order=subtask_order, placements=placements,
+            level_dir=level_dir, auto_reset=False, track_metrics=False)
+        lv = self._b.level
+        self.world = SimpleNamespace(width=lv.width, height=lv.height,
+                                     perimeter=2 * (lv.width + lv.height), arglist=arglist)
+        self.recipes = list(lv.recipes)
+        self.all_subtasks = [s.name for s in lv.subtasks]
+        self.sim_agents = [_SimAgent(i, self._b.ego_config if i == 0 else self._b.partner_config)
+                           for i in range(lv.num_agents)]
+        self.termination_info = ""
+        self.successful = False
+        self.collisions = []
+        self.agent_actions = {}
+        self._act = torch.zeros((lv.num_agents, 1), dtype=torch.int32, device=self._b.device)
+        self.reset()
+
+    # -- state mirror ------------------------------------------------------------
+    def _sync(self):
+        lv = self._b.level
+        s = self._b.snapshot()
+        self.t = int(s["t"][0])
+        self.completed_subtasks = [int(v) for v in s["completed"][0]]
+        self.goal_objects_count = [int(v) for v in s["goal_count"][0]]
+        items, agents, order = s["items"][0], s["agents"][0], s["order"][0]
+        objs = {}
+        for g in order:
+            if g < 0:
+                continue
+            members = [i for i in range(lv.num_items) if items[i][3] == g]
+            contents = [_Content(lv.items[i][0], int(items[i][2])) for i in members]
+            objs[int(g)] = _Object(contents, (int(items[g][0]), int(items[g][1])), items[g][4] >= 0)
+        self.world.objects_in_order = [objs[int(g)] for g in order if g >= 0]
+        for a, ag in enumerate(self.sim_agents):
+            ag.location = (int(agents[a][0]), int(agents[a][1]))
+            ag.holding = objs.get(int(agents[a][2])) if agents[a][2] >= 0 else None
+        self._error = int(s["error"][0])
+        self.rep = self._render()
+
+    def _render(self):
+        """world.update_display + agents (overcooked_environment.py:442-446, world.py:38-48)."""
+        lv = self._b.level
+        glyph = [" ", "-", "/", "*"]
+        rep = [[glyph[int(lv.cells[y][x])] for x in range(lv.width)] for y in range(lv.height)]
+        objs = self.world.objects_in_order
+        for o in objs:
+            rep[o.location[1]][o.location[0]] = str(o)
+        for o in objs:
+            if o.name == "Tomato":
+                rep[o.location[1]][o.location[0]] = str(o)
+        for ag in self.sim_agents:
+            rep[ag.location[1]][ag.location[0]] = str(ag)
+        return rep
+
+    def __str__(self):
+        return "\n".join("".join(c + " " for c in row) for row in self.rep)
+
+    def display(self):
+        self.rep = self._render()
+
+    def get_agent_names(self):
+        return [a.name for a in self.sim_agents]
+
+    # -- API ---------------------------------------------------------------------
+    def reset(self):
+        self._b.reset()
+        self.termination_info = ""
+        self.successful = False
+        self.collisions = []
+        self._sync()
+
+    def step(self, action_dict):
+        for a, ag in enumerate(self.sim_agents):
+            act = tuple(int(v) for v in action_dict[ag.name])        # KeyError like the reference (:217)
+            if act not in _CODE_OF:
+                raise ValueError("action %r is not a unit move" % (act,))
+            ag.action = act
+            self._act[a, 0] = _CODE_OF[act]
+        reward, done, shaping = self._b.step(self._act, auto_reset=False)
+        r, d = int(reward.item()), bool(done.item())
+        sh = shaping.cpu().numpy()
+        self._sync()
+        T = self._b.level.max_num_timesteps
+        if d and T and self.t >= T:
+            self.termination_info = "Terminating because passed {} timesteps".format(T)
+            self.successful = False
+        elif d:
+            self.termination_info = "Terminating because all deliveries were completed"
+            self.successful = True
+        else:
+            self.termination_info = ""
+            self.successful = False
+        info = {"t": self.t, "repr_obs": self.rep, "done": d,
+                "termination_info": self.termination_info,
+                "agent_0_reward_shaping": float(sh[0, 0]),
+                "agent_1_reward_shaping": float(sh[1, 0])}
+        return r, d, info
+
+    def close(self):
+        return
+
+
+# ---------------------------------------------------------------------------------
+# spaces: gym / gymnasium if importable, else a plain description with the same facts
+# ---------------------------------------------------------------------------------
+class SpaceSpec:
+    """Stand-in for gym.spaces.* when neither gym nor gymnasium is installed."""
+
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.__dict__.update(kw)
+
+    def __repr__(self):
+        return "SpaceSpec(%s, %s)" % (self.kind, {k: v for k, v in self.__dict__.items() if k != "kind"})
+
+
+def _spaces_module():
+    for name in ("gym", "gymnasium"):
+        try:
+            mod = __import__(name)
+            return mod.spaces
+        except Exception:
+            continue
+    return None
+
+
+def make_spaces(width, height, S, C):
+    """observation_space / action_space exactly as declared at overcooked_env.py:41-85
+    (including the y-bound quirk low=high=height at :62)."""
+    sp = _spaces_module()
+    if sp is not None:
+        loc = sp.Box(low=np.array([0, 0]), high=np.array([width - 1, height - 1]), dtype=np.float32)
+        obs = sp.Dict({
+            "timestep": sp.Box(low=0.0, high=1.0, shape=(1,), dtype=np.float32),
+            "object_encodings_x": sp.Box(low=-1 * width, high=width, shape=(4,), dtype=np.int64),
+            "object_encodings_y": sp.Box(low=height, high=height, shape=(4,), dtype=np.int64),
+            "state_encodings": sp.MultiBinary(4), "is_hidden": sp.MultiBinary(4),
+            "completed_subtasks": sp.MultiBinary(S),
+            "agent1_location": loc, "agent2_location": loc,
+            "agent_is_holding": sp.MultiBinary(2),
+            "agent1_comm": sp.MultiBinary(C), "agent2_comm": sp.MultiBinary(C)})
+        return obs, sp.MultiDiscrete([4, C])
+    box = lambda lo, hi, shape, dt: SpaceSpec("Box", low=lo, high=hi, shape=shape, dtype=dt)
+    mb = lambda n: SpaceSpec("MultiBinary", n=n)
+    loc = box([0, 0], [width - 1, height - 1], (2,), "float32")
+    obs = SpaceSpec("Dict", spaces={
+        "timestep": box(0.0, 1.0, (1,), "float32"),
+        "object_encodings_x": box(-width, width, (4,), "int64"),
+        "object_encodings_y": box(height, height, (4,), "int64"),
+        "state_encodings": mb(4), "is_hidden": mb(4), "completed_subtasks": mb(S),
+        "agent1_location": loc, "agent2_location": loc, "agent_is_holding": mb(2),
+        "agent1_comm": mb(C), "agent2_comm": mb(C)})
+    return obs, SpaceSpec("MultiDiscrete", nvec=[4, C])
+
+
+# ---------------------------------------------------------------------------------
+# pantheonrl plumbing: use the real SimultaneousEnv when importable, else a stand-in
+# that replays MultiAgentEnv.step/reset (multiagentenv.py:149-243) for 2 players
+# ---------------------------------------------------------------------------------
+def _simultaneous_base():
+    try:
+        from pantheonrl.common.multiagentenv import SimultaneousEnv
+        return SimultaneousEnv
+    except Exception:
+        return _SimultaneousEnvStandIn
+
+
+class _SimultaneousEnvStandIn:
+    def __init__(self, partners=None):
+        self.ego_ind = 0
+        self.n_players = 2
+        self.partners = [list(partners)] if partners else [[]]
+        self.partnerids = [0]
+        self._players = tuple()
+        self._obs = tuple()
+        self._old_ego_obs = None
+        self.should_update = [False]
+        self.total_rews = [0, 0]
+        self.ego_moved = False
+        self.ego_extractor = lambda ob: ob
+
+    def getDummyEnv(self, player_num):
+        return self
+
+    def set_ego_extractor(self, fn):
+        self.ego_extractor = fn
+
+    def add_partner_agent(self, agent, player_num=1):
+        if player_num == self.ego_ind:
+            raise ValueError("Ego agent is not set by the environment")
+        self.partners[0].append(agent)
+
+    def set_partnerid(self, agent_id, player_num=1):
+        assert 0 <= agent_id < len(self.partners[0])
+        self.partnerids[0] = agent_id
+
+    def resample_partner(self):
+        self.partnerids = [(self.partnerids[0] + 1) % len(self.partners[0])]   # round robin (:117-124)
+
+    def _get_actions(self, players, obs, ego_act=None):
+        actions = []
+        for player, ob in zip(players, obs):
+            if player == self.ego_ind:
+                actions.append(ego_act)
+            else:
+                agent = self.partners[0][self.partnerids[0]]
+                actions.append(agent.get_action(ob))
+                if not self.should_update[0]:
+                    agent.update(self.total_rews[player], False)
+                self.should_update[0] = True
+        return np.array(actions)
+
+    def _update_players(self, rews, done):
+        if self.should_update[0]:
+            self.partners[0][self.partnerids[0]].update(rews[1], done)
+        for i in range(2):
+            self.total_rews[i] += rews[i]
+
+    def n_step(self, actions):
+        (o0, o1), r, d, i = self.multi_step(actions[0], actions[1])
+        return (0, 1), (o0, o1), r, d, i
+
+    def n_reset(self):
+        o0, o1 = self.multi_reset()
+        return (0, 1), (o0, o1)
+
+    def step(self, action):
+        ego_rew = 0.0
+        acts = self._get_actions(self._players, self._obs, action)
+        self._players, self._obs, rews, done, info = self.n_step(acts)
+        info["_partnerid"] = self.partnerids
+        self._update_players(rews, done)
+        ego_rew += rews[self.ego_ind] if self.ego_moved else self.total_rews[self.ego_ind]
+        self.ego_moved = True
+        if done:
+            return self.ego_extractor(self._old_ego_obs), ego_rew, done, info   # previous obs (:206-208)
+        ego_obs = self._obs[self._players.index(self.ego_ind)]
+        self._old_ego_obs = ego_obs
+        return self.ego_extractor(ego_obs), ego_rew, done, info
+
+    def reset(self):
+        self.resample_partner()
+        self._players, self._obs = self.n_reset()
+        self.should_update = [False]
+        self.total_rews = [0, 0]
+        self.ego_moved = False
+        ego_obs = self._obs[self._players.index(self.ego_ind)]
+        self._old_ego_obs = ego_obs
+        return self.ego_extractor(ego_obs)
+
+
+def _make_multi_env_class():
+    Base = _simultaneous_base()
+
+    class OvercookedMultiEnv(Base):
+        """``OvercookedMultiEnv(arglist, ego_agent_idx=0, baselines=False)``."""
+
+        def __init__(self, arglist, ego_agent_idx=0, baselines=False, device="cuda",
+                     subtask_order=None, placements=None, level_dir=None):
+            super().__init__()
+            self.arglist = arglist
+            self.ego_agent_idx = ego_agent_idx
+            if baselines:
+                np.random.seed(0)                       # overcooked_env.py:34
+            if _arg(arglist, "num_agents") != 2:
+                raise ValueError("the gym_comm wrapper drives exactly 2 agents "
+                                 "(overcooked_env.py:250-262 sets agent-0 and agent-1 only)")
+            self._b = BatchedOvercooked(
+                _arg(arglist, "level"), num_agents=2, num_envs=1,
+                max_num_timesteps=_arg(arglist, "max_num_timesteps", 100),
+                max_num_subtasks=_arg(arglist, "max_num_subtasks", 14),
+                ego_config=dict(_arg(arglist, "ego_config", {}) or {}),
+                partner_config=dict(_arg(arglist, "partner_config", {}) or {}),
+                num_communication=_arg(arglist, "num_communication", 10),
+                communication_on=_arg(arglist, "communication_on", False),
+                ego_led=_arg(arglist, "ego_led", False),
+                fow_radius=_arg(arglist, "fow_radius", 2), ego_agent_idx=ego_agent_idx,
+                device=device, subtask_order=subtask_order, placements=placements,
+                level_dir=level_dir, auto_reset=False, track_metrics=False)
+            self.base_env = OvercookedEnvironment(arglist, _batch=self._b)
+            lv = self._b.level
+            self.lA = len(NAV_ACTIONS)
+            self.observation_space, self.action_space = make_spaces(
+                lv.width, lv.height, lv.num_subtasks, self._b.C)
+            self._layout = obs_layout(lv.num_subtasks, self._b.C)
+            self._act = torch.zeros((4, 1), dtype=torch.int32, device=self._b.device)
+            self.multi_reset()
+
+        @property
+        def per_agent_communications(self):
+            c = self._b.comm.cpu().numpy()[:, 0]
+            out = []
+            for k in range(2):
+                v = np.zeros(self._b.C)
+                if c[k] >= 0:
+                    v[c[k]] = 1
+                out.append(v)
+            return out
+
+        def _obs_dicts(self, obs, ts):
+            o = obs.cpu().numpy()[:, :, 0].astype(np.int64)
+            t = ts.cpu().numpy()
+            ego_blind = bool(self._b.ego_config["BLIND"])
+            out = []
+            for v in range(2):
+                d = {"timestep": np.array((t[0],))}
+                for k, (a, b) in self._layout.items():
+                    d[k] = o[v, a:b].copy()
+                if not ego_blind:                       # bool pair unless the EGO is BLIND (:154)
+                    d["agent_is_holding"] = d["agent_is_holding"].astype(bool)
+                d["agent1_comm"] = d["agent1_comm"].astype(np.float64)
+                d["agent2_comm"] = d["agent2_comm"].astype(np.float64)
+                out.append(d)
+            return out[0], out[1]
+
+        def get_observation2(self, agent_idx, radius=1000):
+            if radius != self._b._obs_cfg.fow_radius:
+                saved = self._b._obs_cfg.fow_radius
+                self._b._obs_cfg.fow_radius = int(radius)
+                try:
+                    obs, ts = self._b.observe()
+                    return self._obs_dicts(obs, ts)[agent_idx]
+                finally:
+                    self._b._obs_cfg.fow_radius = saved
+            obs, ts = self._b.observe()
+            return self._obs_dicts(obs, ts)[agent_idx]
+
+        def multi_step(self, ego_action, alt_action):
+            self._act[:, 0] = torch.tensor([int(ego_action[0]), int(ego_action[1]),
+                                            int(alt_action[0]), int(alt_action[1])], dtype=torch.int32)
+            for v in (ego_action[0], alt_action[0]):
+                if not 0 <= int(v) < 4:
+                    raise IndexError("list index out of range")        # NAV_ACTIONS[idx] (:248)
+            obs, ts, rew, done = self._b.multi_step(self._act, auto_reset=False)
+            o0, o1 = self._obs_dicts(obs, ts)
+            r = float(rew.item())
+            self.base_env._sync()
+            return (o0, o1), (r, r), bool(done.item()), {}
+
+        def multi_reset(self):
+            self.base_env.reset()
+            obs, ts = self._b.observe()
+            return self._obs_dicts(obs, ts)
+
+        def cost_fn(self):
+            return 1
+
+        def render(self, mode="human", close=False):
+            print(str(self.base_env))
+
+    return OvercookedMultiEnv
+
+
+OvercookedMultiEnv = _make_multi_env_class()
+
+
+def register(gym_module=None):
+    """Point the reference's registry ids at these classes
+    (gym_comm/__init__.py:3-5, gym_cooking/__init__.py:3-6)."""
+    if gym_module is None:
+        import gym as gym_module
+    reg = gym_module.envs.registration.register
+    reg(id="OvercookedMultiCommEnv-v0", entry_point="gym_comm_amd.envs:OvercookedMultiEnv")
+    reg(id="overcookedEnv-v0", entry_point="gym_comm_amd.envs:OvercookedEnvironment")

@@ -1,0 +1,147 @@
+/* oc_hip.h -- C ABI of the MI355X-native batched Overcooked stepper (liboc_hip.so).
+ *
+ * The reference has no FFI: its hot path is a Python object API.  These entry
+ * points are what a binding for that path calls instead of the Python loops
+ * (INTEGRATION.md shows the ctypes stub).  Each one cites the reference code it
+ * replaces; paths are relative to the reference root.
+ *
+ * Conventions
+ *   - Every env of a call shares one level (oc_level_t).  N envs are stepped by one
+ *     launch, one lane per env.
+ *   - All tensors are env-major struct-of-arrays: row r of a [R][n] tensor is the n
+ *     consecutive values of field r, so a wave's 64 lanes read 256 contiguous bytes.
+ *   - Pointers are raw DEVICE pointers owned by the caller (PyTorch-ROCm tensors in
+ *     our host code).  The library never allocates or frees tensor memory and never
+ *     synchronises: calls are asynchronous on `stream` (a hipStream_t passed as
+ *     void*, NULL = the default stream).  The caller serialises calls that touch the
+ *     same state.
+ *   - Return value: 0 on success, otherwise a hipError_t value or one of the
+ *     OC_E_* codes below; oc_last_error() describes the most recent failure of the
+ *     calling thread.
+ */
+#ifndef OC_HIP_H
+#define OC_HIP_H
+
+#include <stdint.h>
+
+#include "oc_level.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OC_ABI_VERSION 1
+#define OC_API __attribute__((visibility("default")))
+
+enum {
+  OC_OK = 0,
+  OC_E_BADARG = -1,  /* NULL pointer, negative n, bad blob, unsupported A/M */
+  OC_E_NODEVICE = -2 /* no HIP device / runtime failure before launch */
+};
+
+typedef struct oc_level oc_level_t; /* opaque; device-resident static tables */
+
+/* ---- state tensor ----------------------------------------------------------
+ * int32 [oc_state_words()][n].  Rows (A agents, M items):
+ *   row a           agent a : x | y<<4 | (held_group+1)<<8           (0 = empty hands)
+ *   row A+i         item i  : x | y<<4 | chopped<<8 | group<<9 | (holder+1)<<12 | seq<<16
+ *                             group  = smallest item id in the same Object
+ *                             holder = agent holding that Object
+ *                             seq    = rank of the Object in world.objects iteration
+ *                                      order (initial items 0..M-1, the k-th merge of
+ *                                      the episode gets M+k)
+ *   row A+M         t | completed_subtasks_bitmask<<16
+ *   row A+M+1       goal_objects_count bits | merge_counter<<16 | error_flags<<24
+ * Replaces the World / SimAgent object graph (gym_cooking/utils/world.py:14-320,
+ * utils/agent.py:258-314, utils/core.py:149-237). */
+
+/* ---- observation tensor ----------------------------------------------------
+ * int32 [2][oc_obs_rows()][n]: viewer 0 then viewer 1; rows per viewer, in the key
+ * order of OvercookedMultiEnv.get_observation2
+ * (gym_comm/envs/overcooked_env.py:145-157) minus `timestep`:
+ *   object_encodings_x[4] object_encodings_y[4] state_encodings[4] is_hidden[4]
+ *   completed_subtasks[S] agent1_location[2] agent2_location[2] agent_is_holding[2]
+ *   agent1_comm[C] agent2_comm[C]                         => 22 + S + 2C rows
+ * `timestep` (t / max_num_timesteps, fp64) is the same for both viewers and goes to
+ * its own double[n] tensor. */
+
+typedef struct {
+  int32_t fow_radius;   /* arglist.fow_radius */
+  int32_t blind_mask;   /* bit0: ego_config["BLIND"], bit1: partner_config["BLIND"] */
+  int32_t num_comm;     /* arglist.num_communication (C) */
+  int32_t reserved;
+} oc_obs_cfg;
+
+typedef struct {
+  oc_obs_cfg obs;
+  int32_t communication_on; /* arglist.communication_on */
+  int32_t ego_led;          /* arglist.ego_led */
+  int32_t ego_agent_idx;    /* OvercookedMultiEnv(ego_agent_idx=...) */
+  int32_t can_move_mask;    /* bit0: ego_config["CAN_MOVE"], bit1: partner_config["CAN_MOVE"] */
+} oc_wrap_cfg;
+
+/* metrics accumulated by the step kernels when `metrics` != NULL (int64[8], device) */
+enum {
+  OC_MET_ENV_STEPS = 0,
+  OC_MET_EPISODES = 1,      /* steps that returned done */
+  OC_MET_SUCCESSES = 2,     /* done because every delivery was made */
+  OC_MET_REWARD_SUM = 3,    /* sum of the sparse integer reward */
+  OC_MET_COMPLETED_SUM = 4, /* sum over finished episodes of completed subtasks */
+  OC_MET_ERRORS = 5,        /* env-steps that raised an OC_ERR_* flag */
+  OC_MET_COUNT = 8
+};
+
+OC_API int oc_abi_version(void);
+OC_API const char *oc_last_error(void);
+
+/* Upload one compiled level (include/oc_level.h blob, HOST pointer) to the current
+ * device.  Replaces the per-reset static work of OvercookedEnvironment.reset():
+ * load_level, run_recipes, make_reachability_graph, cache_distances
+ * (gym_cooking/envs/overcooked_environment.py:180-206). */
+OC_API int oc_level_create(const int32_t *blob, int32_t n_words, oc_level_t **out);
+OC_API int oc_level_destroy(oc_level_t *lv);
+OC_API int32_t oc_state_words(const oc_level_t *lv);                 /* A + M + 2 */
+OC_API int32_t oc_obs_rows(const oc_level_t *lv, int32_t num_comm);  /* 22 + S + 2C */
+
+/* OvercookedEnvironment.reset() (overcooked_environment.py:180-206) for every env
+ * whose mask[n] != 0 (mask NULL = all). */
+OC_API int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, int64_t n, void *stream);
+
+/* OvercookedEnvironment.step() (overcooked_environment.py:211-241): check_collisions
+ * (:578-613), execute_navigation -> interact (:615-618, utils/interact.py:4-75),
+ * done (:243-270), reward (:399-432), calculate_reward_shaping for sim agents 0 and 1
+ * (:272-397).
+ *   actions  int32 [A][n]  action codes 0..4 (OC_ACT_*), one row per sim agent
+ *   reward   int32 [n]     the sparse reward
+ *   done     int32 [n]
+ *   shaping  double[2][n]  info["agent_0_reward_shaping"], info["agent_1_reward_shaping"]
+ *   auto_reset != 0: an env that returns done is reset in the same launch (its state
+ *   tensor then holds the fresh episode; reward/done/shaping are the terminal step's).
+ *   metrics  int64 [8] or NULL */
+OC_API int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_t *reward,
+            int32_t *done, double *shaping, int32_t auto_reset, int64_t *metrics, int64_t n,
+            void *stream);
+
+/* OvercookedMultiEnv.get_observation2 for both viewers
+ * (gym_comm/envs/overcooked_env.py:105-159).
+ *   comm     int32 [2][n]  per_agent_communications as the index of the set bit, -1 = zeros */
+OC_API int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, const oc_obs_cfg *cfg,
+           int32_t *obs, double *timestep, int64_t n, void *stream);
+
+/* OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282) in ONE
+ * launch: action decoding + CAN_MOVE gating + comm update (:220-262), the base step,
+ * both observations, and the shaped reward (r - s0) - s1 (:282).  2-agent levels only
+ * (the reference's wrapper only drives agent-0 and agent-1).
+ *   actions  int32 [4][n]  ego move (0..3), ego comm, alt move, alt comm
+ *   comm     int32 [2][n]  in/out, persists across resets (:89-91,284-297)
+ *   reward   double[n]     shaped reward, identical for both agents
+ *   sparse   int32 [n] or NULL  the unshaped integer reward */
+OC_API int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
+                  const oc_wrap_cfg *cfg, int32_t *obs, double *timestep, double *reward,
+                  int32_t *done, int32_t *sparse, int32_t auto_reset, int64_t *metrics, int64_t n,
+                  void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -736,3 +736,21 @@ OC_EXPORT void oc_oracle_batch_multi_step(void **envs, int64_t n0, int64_t n1, i
     }
   }
 }
+
+/* snapshot of envs [0, n): arrays are [n][M][5], [n][M], [n][A][3], [n][2], [n][S], [n][S],
+ * plus err[n] */
+OC_EXPORT void oc_oracle_batch_snapshot(void **envs, int64_t n, int32_t *items, int32_t *order,
+                                        int32_t *agents, int32_t *misc, int32_t *completed,
+                                        int32_t *goalcnt, int32_t *err) {
+  for (int64_t i = 0; i < n; i++) {
+    const Env *e = (const Env *)envs[i];
+    oc_oracle_snapshot(e, items + i * e->M * 5, order + i * e->M, agents + i * e->A * 3, misc + i * 2,
+                       completed + i * e->S, goalcnt + i * e->S);
+    err[i] = e->err;
+  }
+}
+
+OC_EXPORT void oc_oracle_batch_reset(void **envs, int64_t n, const int32_t *mask) {
+  for (int64_t i = 0; i < n; i++)
+    if (!mask || mask[i]) env_reset((Env *)envs[i]);
+}

@@ -56,6 +56,8 @@ def lib():
         L.oc_oracle_batch_multi_step.argtypes = (
             [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
              _I32P, _I32P] + [ctypes.c_int] * 7 + [_I32P, _F64P, _F64P, _I32P, ctypes.c_int])
+        L.oc_oracle_batch_snapshot.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64] + [_I32P] * 7
+        L.oc_oracle_batch_reset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, _I32P]
         _lib = L
     return _lib
 
@@ -165,9 +167,26 @@ class OracleBatch:
         for t in ts:
             t.join()
 
-    def reset(self):
-        for i in range(self.n):
-            lib().oc_oracle_reset(self._handles[i])
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.int32)
+            m = _p32(mask)
+        lib().oc_oracle_batch_reset(self._handles, self.n, m)
+
+    def snapshot_all(self):
+        n, A, M, S = self.n, self.A, self.M, self.S
+        items = np.zeros((n, M, 5), np.int32)
+        order = np.zeros((n, M), np.int32)
+        agents = np.zeros((n, A, 3), np.int32)
+        misc = np.zeros((n, 2), np.int32)
+        comp = np.zeros((n, S), np.int32)
+        gc = np.zeros((n, S), np.int32)
+        err = np.zeros(n, np.int32)
+        lib().oc_oracle_batch_snapshot(self._handles, n, _p32(items), _p32(order), _p32(agents),
+                                       _p32(misc), _p32(comp), _p32(gc), _p32(err))
+        return {"items": items, "order": order, "agents": agents, "t": misc[:, 0].copy(),
+                "nobj": misc[:, 1].copy(), "completed": comp, "goal_count": gc, "error": err}
 
     def step(self, actions, auto_reset=False):
         actions = np.ascontiguousarray(actions, dtype=np.int32)

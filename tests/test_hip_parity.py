@@ -1,0 +1,183 @@
+"""-m gpu: the hand-written HIP path (through the C ABI, gym_comm_amd.BatchedOvercooked)
+against (1) the golden vectors recorded from the reference and (2) the CPU oracle on
+seeded inputs.  Integer state, rewards, done flags and observations must be equal;
+fp64 shaping / rewards / timesteps must have identical bits."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import compile_for, golden_files, load_golden
+from hip_util import assert_snapshots_equal, bits, scripted_then_random
+
+pytestmark = pytest.mark.gpu
+
+BASE = golden_files("base_")
+WRAP = golden_files("wrap_")
+
+
+def _env(lv, n, **kw):
+    from gym_comm_amd.batched import BatchedOvercooked
+    return BatchedOvercooked(lv, num_envs=n, **kw)
+
+
+@pytest.mark.parametrize("path", BASE, ids=[os.path.basename(p) for p in BASE])
+def test_base_step_matches_reference_golden(path):
+    """Replay every recorded tape of OvercookedEnvironment.step/reset; 96 lanes (one and
+    a half waves) get the same actions and must all reproduce the reference."""
+    from gym_comm_amd.state import unpack_state
+    z, st = load_golden(path)
+    lv = compile_for(st)
+    n = 96
+    env = _env(lv, n, auto_reset=False)
+    K = len(z["t"])
+    acts = torch.from_numpy(np.repeat(z["actions"].astype(np.int32)[:, :, None], n, axis=2)).cuda()
+    hist_state, hist_r, hist_d, hist_s = [], [], [], []
+    for k in range(K):
+        if z["reset_before"][k]:
+            env.reset()
+        r, d, sh = env.step(acts[k])
+        hist_state.append(env.state.clone())
+        hist_r.append(r.clone()); hist_d.append(d.clone()); hist_s.append(sh.clone())
+    S = torch.stack(hist_state).cpu().numpy()          # [K][W][n]
+    R = torch.stack(hist_r).cpu().numpy()
+    Dn = torch.stack(hist_d).cpu().numpy()
+    Sh = torch.stack(hist_s).cpu().numpy()             # [K][2][n]
+    assert (R == z["reward"][:, None]).all()
+    assert (Dn == z["done"][:, None]).all()
+    assert (bits(Sh) == z["shaping_bits"][:, :, None]).all()
+    for lane in (0, 63, 64, 95):
+        snap = unpack_state(S[:, :, lane].T, lv.num_agents, lv.num_items, lv.num_subtasks)
+        assert (snap["items"] == z["items"][:, :, :5]).all(), lane
+        assert (snap["order"] == z["order"]).all(), lane
+        assert (snap["agents"] == z["agents"]).all(), lane
+        assert (snap["t"] == z["t"]).all(), lane
+        assert (snap["completed"] == z["completed"]).all(), lane
+        assert (snap["goal_count"] == z["goal_count"]).all(), lane
+        assert (snap["nobj"] == z["nobj"]).all(), lane
+        assert (snap["error"] == 0).all(), lane
+
+
+def _wrap_env(st, lv, n, **kw):
+    return _env(lv, n, ego_config=st["ego_config"], partner_config=st["partner_config"],
+                num_communication=st["num_communication"], communication_on=st["communication_on"],
+                ego_led=st["ego_led"], fow_radius=st["fow_radius"],
+                ego_agent_idx=st["ego_agent_idx"], **kw)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "step+obs"])
+@pytest.mark.parametrize("path", WRAP, ids=[os.path.basename(p) for p in WRAP])
+def test_wrapper_matches_reference_golden(path, fused):
+    """OvercookedMultiEnv.multi_step / multi_reset / get_observation2 tapes, through the
+    fused oc_multi_step kernel and through oc_step + oc_obs."""
+    z, st = load_golden(path)
+    lv = compile_for(st)
+    n = 70
+    env = _wrap_env(st, lv, n, auto_reset=False)
+    C = st["num_communication"]
+    # observation right after multi_reset()
+    obs, ts = env.observe()
+    obs_h, ts_h = obs.cpu().numpy(), ts.cpu().numpy()
+    for v in range(2):
+        assert (obs_h[v, :, :] == z["reset_obs"][v][:, None]).all()
+    assert (bits(ts_h) == z["reset_ts_bits"][0]).all()
+    K = len(z["done"])
+    acts = torch.from_numpy(np.repeat(z["actions"].astype(np.int32)[:, :, None], n, axis=2)).cuda()
+    H_obs, H_ts, H_r, H_d = [], [], [], []
+    can = (1 if st["ego_config"]["CAN_MOVE"] else 0) | (2 if st["partner_config"]["CAN_MOVE"] else 0)
+    for k in range(K):
+        if z["reset_before"][k]:
+            env.reset()
+        if fused:
+            o, t, r, d = env.multi_step(acts[k])
+        else:
+            # the wrapper's host logic spelled out with the two separate kernels
+            a = acts[k]
+            noop = torch.full_like(a[0], 4)
+            em = a[0] if (can & 1) else noop
+            am = a[2] if (can & 2) else noop
+            base = torch.stack([em, am] if st["ego_agent_idx"] == 0 else [am, em]).contiguous()
+            neg = torch.full_like(a[1], -1)
+            env.comm[0] = a[1] if st["communication_on"] else neg
+            env.comm[1] = a[3] if (st["communication_on"] and not st["ego_led"]) else neg
+            rr, d, sh = env.step(base)
+            r = (rr.double() - sh[0]) - sh[1]
+            o, t = env.observe()
+        H_obs.append(o.clone()); H_ts.append(t.clone()); H_r.append(r.clone()); H_d.append(d.clone())
+    O = torch.stack(H_obs).cpu().numpy()      # [K][2][F][n]
+    T = torch.stack(H_ts).cpu().numpy()
+    R = torch.stack(H_r).cpu().numpy()
+    Dn = torch.stack(H_d).cpu().numpy()
+    assert (Dn == z["done"][:, None]).all()
+    assert (bits(R) == z["rew_bits"][:, None]).all()
+    assert (O == z["obs"][:, :, :, None]).all()
+    assert (bits(T) == z["ts_bits"][:, 0][:, None]).all()
+    assert env.F == 22 + lv.num_subtasks + 2 * C
+
+
+CASES = [
+    ("open-divider_tomato", 2, 100), ("full-divider_salad", 2, 120), ("partial-divider_tl", 3, 100),
+    ("open-divider_salad", 2, 150), ("open-divider_tl", 3, 150), ("partial-divider_tomato", 4, 60),
+    ("open-divider_tl", 2, 200), ("partial-divider_salad", 4, 90),
+]
+
+
+@pytest.mark.parametrize("level,A,T", CASES, ids=["%s-a%d" % (c[0], c[1]) for c in CASES])
+def test_step_matches_oracle_seeded(level, A, T, oracle_lib):
+    """Seeded action streams, every env different, auto-reset on: full state compare with
+    the oracle after every step (ragged batch: 1000 envs = 15 waves + a 40-lane tail)."""
+    from gym_comm_amd import compiler
+    lv = compiler.compile_level(level, A, T)
+    n, steps = 1000, 260
+    rng = np.random.default_rng(1234 + A)
+    acts = scripted_then_random(rng, level, steps, A, n)
+    ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
+    env = _env(lv, n, auto_reset=True)
+    acts_d = torch.from_numpy(acts).cuda()
+    tot_r = tot_d = 0
+    for k in range(steps):
+        r, d, sh = env.step(acts_d[k])
+        ro, do, sho = ora.step(acts[k], auto_reset=True)
+        hs = env.snapshot()
+        os_ = ora.snapshot_all()
+        clean = (os_["error"] == 0) & (hs["error"] == 0)
+        # both sides must flag the reference's self-corrupting corner on the same envs
+        assert ((os_["error"] != 0) == (hs["error"] != 0)).all(), (level, k)
+        ctx = "%s step %d" % (level, k)
+        assert np.array_equal(r.cpu().numpy()[clean], ro[clean]), ctx
+        assert np.array_equal(d.cpu().numpy()[clean], do[clean]), ctx
+        assert np.array_equal(bits(sh.cpu().numpy())[:, clean], bits(sho)[:, clean]), ctx
+        assert_snapshots_equal(hs, os_, ctx, where=clean)
+        assert clean.mean() > 0.9
+        tot_r += int(r.sum().item()); tot_d += int(d.sum().item())
+    m = env.read_metrics()
+    assert m["env_steps"] == n * steps
+    assert m["episodes"] == tot_d and m["reward_sum"] == tot_r
+    assert tot_d > 0 and tot_r > 0
+
+
+@pytest.mark.parametrize("level,T,C,radius", [("open-divider_tomato", 100, 2, 2),
+                                              ("full-divider_salad", 120, 5, 1),
+                                              ("open-divider_tl", 150, 3, 3)])
+def test_multi_step_matches_oracle_seeded(level, T, C, radius, oracle_lib):
+    from gym_comm_amd import compiler
+    lv = compiler.compile_level(level, 2, T)
+    n, steps = 777, 200
+    rng = np.random.default_rng(99)
+    mv = scripted_then_random(rng, level, steps, 2, n, nact=4)
+    cm = rng.integers(0, C, (steps, 2, n)).astype(np.int32)
+    acts = np.stack([mv[:, 0], cm[:, 0], mv[:, 1], cm[:, 1]], axis=1).astype(np.int32)
+    ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
+    comm = np.zeros((2, n), np.int32)
+    env = _env(lv, n, num_communication=C, fow_radius=radius, auto_reset=True)
+    acts_d = torch.from_numpy(acts).cuda()
+    for k in range(steps):
+        o, t, r, d = env.multi_step(acts_d[k])
+        oo, to, ro, do = ora.multi_step(acts[k], comm, radius, 0, C, auto_reset=True)
+        ctx = "%s step %d" % (level, k)
+        assert np.array_equal(d.cpu().numpy(), do), ctx
+        assert np.array_equal(bits(r.cpu().numpy()), bits(ro)), ctx
+        assert np.array_equal(o.cpu().numpy(), oo), ctx
+        assert np.array_equal(bits(t.cpu().numpy()), bits(to)), ctx
+        assert np.array_equal(env.comm.cpu().numpy(), comm), ctx

@@ -1,0 +1,187 @@
+"""CPU-side checks (no GPU): level compiler vs the golden static tables, the C ABI
+surface, host argument handling, and the multi-process sharding/metrics path on gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, compile_for, golden_files, load_golden
+
+ALL = golden_files("base_") + golden_files("wrap_")
+
+
+@pytest.mark.parametrize("path", ALL, ids=[os.path.basename(p) for p in ALL])
+def test_level_compiler_matches_reference_static_tables(path):
+    from gym_comm_amd import compiler as C, levels as L
+    z, st = load_golden(path)
+    lv = C.compile_level(st["level"], st["num_agents"], st["max_num_timesteps"])
+    assert (lv.width, lv.height) == (st["width"], st["height"])
+    assert (lv.cells == np.array(st["cells"])).all()
+    assert (lv.dist == np.array(st["dist"])).all()          # World.get_path_distance_between, all pairs
+    assert [list(i) for i in lv.items] == st["items"]       # world.objects iteration order
+    assert [list(a) for a in lv.agents] == st["agents"]
+    tid = {n: i for i, n in enumerate(L.TYPE_NAME)}
+    mine = sorted((C.KIND_NAME[s.kind], s.goal_types) for s in lv.subtasks)
+    ref = sorted((k, tuple(sorted(tid[n] for a in args for n in a.split("-")))) for k, args in st["subtasks"])
+    assert mine == ref
+    assert sorted(s.name for s in lv.subtasks) == sorted("%s(%s)" % (k, ", ".join(a)) for k, a in st["subtasks"])
+    lv2 = compile_for(st)                                    # explicit (recorded) order
+    assert [[C.KIND_NAME[s.kind], list(s.args)] for s in lv2.subtasks] == st["subtasks"]
+    assert [L.TYPE_NAME[t] for t in lv.pair_types[1:]] == st["recipe0_names"]
+    assert lv.max_path == 2 * (lv.width + lv.height) + 1
+
+
+def test_blob_layout_roundtrip():
+    from gym_comm_amd import compiler as C
+    lv = C.compile_level("partial-divider_tl", 3, 77, ego_allergic=True)
+    b = lv.blob
+    assert b[0] == C.MAGIC and b[1] == C.VERSION and b[23] == b.size
+    assert list(b[2:9]) == [7, 7, 3, 4, 6, 77, 29]
+    assert b[9] == 1
+    lv = C.compile_level("partial-divider_tl", 3, 77, partner_allergic=True)
+    assert lv.blob[9] == 0b110
+    n = 49
+    assert (b[b[16]:b[16] + n].reshape(7, 7) == lv.cells).all()
+    assert (b[b[17]:b[17] + n * n].reshape(n, n) == lv.dist).all()
+
+
+def test_level_errors():
+    from gym_comm_amd import compiler as C
+    with pytest.raises(FileNotFoundError):
+        C.compile_level("no-such-level", 2)
+    with pytest.raises(ValueError):
+        C.compile_level("open-divider_tomato", 5)
+    with pytest.raises(ValueError):
+        C.compile_level("random-open-divider_salad_small", 2)       # needs placements
+    lv = C.compile_level("random-open-divider_salad_small", 2, placements=[(1, 0), (4, 1), (3, 4)])
+    assert [t for t, _, _ in lv.items] == [3, 1, 0] and lv.num_subtasks == 9
+    with pytest.raises(ValueError):
+        C.compile_level("open-divider_tomato", 2, subtask_order=[0, 0, 1])
+    with pytest.raises(ValueError):
+        C.compile_level("open-divider_tomato", 2, subtask_order=["Chop(Onion)", "Chop(Tomato)", "Deliver(Plate-Tomato)"])
+
+
+def test_level_text_parser_matches_builtin(tmp_path):
+    from gym_comm_amd import compiler as C, levels as L
+    txt = "-----t-\n/     l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSimpleTomato\n\n2 1\n4 1\n4 4\n2 4"
+    (tmp_path / "mine.txt").write_text(txt)
+    a = C.compile_level("mine", 2, level_dir=str(tmp_path))
+    b = C.compile_level("open-divider_tomato", 2)
+    assert (a.blob[2:] == b.blob[2:]).all()
+    assert len(L.BUILTIN) == 19
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The library loads without a GPU and exports exactly what include/oc_hip.h declares."""
+    from gym_comm_amd import _lib, build
+    build.build()
+    hdr = open(os.path.join(ROOT, "include", "oc_hip.h")).read()
+    declared = re.findall(r"OC_API\s+[\w\s\*]+?\b(oc_\w+)\s*\(", hdr)
+    assert sorted(declared) == sorted(_lib.SYMBOLS)
+    L = _lib.load()
+    for sym in declared:
+        assert getattr(L, sym) is not None
+    assert L.oc_abi_version() == 1
+    # argument validation happens before any device work
+    assert L.oc_step(None, None, None, None, None, None, 0, None, 0, None) == -1
+    assert b"oc_step" in L.oc_last_error()
+    bad = np.zeros(32, np.int32)
+    h = ctypes.c_void_p()
+    assert L.oc_level_create(bad.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 32, ctypes.byref(h)) == -1
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gym_comm_amd._lib import OcError
+    from gym_comm_amd.batched import BatchedOvercooked
+    with pytest.raises(OcError):
+        BatchedOvercooked("open-divider_tomato", num_envs=4, device="cpu")
+    with pytest.raises(Exception):
+        BatchedOvercooked("open-divider_tomato", num_envs=4, device="cuda")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gym-comm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", "").replace("CPU oracle", "").replace(
+                    "test oracle", "").replace("the oracle", "").replace("oracle/", "").replace(
+                    "oracle)", ""), (f, "product code must not reference the oracle package")
+
+
+def test_unpack_state_roundtrip():
+    from gym_comm_amd.state import unpack_state
+    A, M, S = 2, 4, 3
+    w = np.zeros((A + M + 2, 2), np.int64)
+    for e in range(2):
+        w[0, e] = 2 | (1 << 4)
+        w[1, e] = 5 | (5 << 4) | ((0 + 1) << 8 if e == 1 else 0)
+        for i in range(M):
+            w[A + i, e] = (i + 1) | (i << 4) | (i << 9) | (i << 16)
+    for i in (0, 2):                                      # env 1: items 0+2 merged, held by agent 1
+        w[A + i, 1] = 5 | (5 << 4) | ((1 << 8) if i == 0 else 0) | (0 << 9) | (2 << 12) | (4 << 16)
+    w[A + M, 1] = 17 | (0b101 << 16)
+    w[A + M + 1, 1] = 0b010 | (1 << 16)
+    u = unpack_state(w, A, M, S)
+    assert u["order"].tolist() == [[0, 1, 2, 3], [1, 3, 0, -1]]
+    assert u["nobj"].tolist() == [4, 3]
+    assert u["agents"][1].tolist() == [[2, 1, -1], [5, 5, 0]]
+    assert u["items"][1][2].tolist() == [5, 5, 0, 0, 1]
+    assert u["t"].tolist() == [0, 17] and u["completed"][1].tolist() == [1, 0, 1]
+    assert u["goal_count"][1].tolist() == [0, 1, 0] and u["merge_counter"].tolist() == [0, 1]
+
+
+def test_shard_partition():
+    from gym_comm_amd.dist import shard
+    for total, world in ((8 * 131072, 8), (4096, 3), (5, 8), (0, 2)):
+        got = [shard(total, r, world) for r in range(world)]
+        assert sum(c for _, c in got) == total
+        pos = 0
+        for s, c in got:
+            assert s == pos
+            pos += c
+        assert max(c for _, c in got) - min(c for _, c in got) <= 1
+    with pytest.raises(ValueError):
+        shard(10, 2, 2)
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import gym_comm_amd
+from gym_comm_amd import dist as ocdist
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+start, count = ocdist.shard(1001, rank, world)
+local = torch.tensor([count * 10, rank + 1, rank, 3 * count, 7, 0, 0, 0], dtype=torch.int64)
+g = ocdist.gather_rollout_metrics(local, 1.0 + rank)
+assert g["elapsed_s"] == float(world), g
+assert g["total"]["env_steps"] == 10010, g
+assert g["total"]["episodes"] == sum(range(1, world + 1)), g
+assert len(g["per_rank"]) == world and g["per_rank"][rank][1] == rank + 1
+assert ocdist.rank_seed(5, rank) != ocdist.rank_seed(5, (rank + 1) %% world)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_metrics_allgather_two_ranks_gloo(tmp_path):
+    """world_size 2 on gloo: the N>1 path (shard + end-of-rollout all-gather + max-time)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
