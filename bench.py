@@ -56,39 +56,49 @@ def parse():
     return p.parse_args()
 
 
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may run on, capped at the
+    GPU box's per-GPU CPU share (16)."""
+    if os.environ.get("OC_CPU_THREADS"):
+        return max(1, int(os.environ["OC_CPU_THREADS"]))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 16))
+
+
 def cpu_baseline(level_blob, A, C, wrapper, seconds):
     """The CPU oracle (oracle/oc_oracle.c, the bit-exact restatement of the reference's
     step()+obs) timed on this box's host cores on a bounded sample of the same workload.
     Reported baseline only -- never part of the product path."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     n = 4096
-    steps = 64
+    chunk = 64                                   # steps per C call (one call per thread)
     rng = np.random.default_rng(1234)
     ora = oracle.OracleBatch(level_blob, n, threads=cores)
     if wrapper:
-        acts = np.stack([rng.integers(0, 4, (steps, n)), rng.integers(0, C, (steps, n)),
-                         rng.integers(0, 4, (steps, n)), rng.integers(0, C, (steps, n))],
+        acts = np.stack([rng.integers(0, 4, (chunk, n)), rng.integers(0, C, (chunk, n)),
+                         rng.integers(0, 4, (chunk, n)), rng.integers(0, C, (chunk, n))],
                         axis=1).astype(np.int32)
         comm = np.zeros((2, n), np.int32)
     else:
-        acts = rng.integers(0, 4, (steps, A, n)).astype(np.int32)
-    done_steps = 0
+        acts = rng.integers(0, 4, (chunk, A, n)).astype(np.int32)
+    steps = 0
     t0 = time.perf_counter()
-    k = 0
     while True:
         if wrapper:
-            ora.multi_step(acts[k % steps], comm, 2, 0, C, auto_reset=True)
+            ora.multi_rollout(acts, comm, 2, 0, C, auto_reset=True)
         else:
-            ora.step(acts[k % steps], auto_reset=True)
-        k += 1
-        done_steps += n
+            ora.rollout(acts, auto_reset=True)
+        steps += chunk
         el = time.perf_counter() - t0
-        if el >= seconds and k >= 8:
+        if el >= seconds:
             break
-    return {"value": done_steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d steps of the same workload (%.1f s wall), C oracle, %d threads"
-                      % (n, k, el, cores)}
+    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d steps of the same workload (%.1f s wall), C oracle "
+                      "(oracle/oc_oracle.c), %d threads" % (n, steps, el, cores)}
 
 
 def main():

@@ -34,6 +34,17 @@ class OcError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).
+    Our library must bind to THAT runtime instance -- device pointers and streams come
+    from torch -- so make sure it is the one already loaded when liboc_hip.so resolves
+    its libamdhip64.so.7 dependency."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def load(path=None):
     """Load (once) and type the library.  Raises if it is missing."""
     global _lib
@@ -44,6 +55,7 @@ def load(path=None):
         raise OcError(
             "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
             " (there is no CPU fallback)" % path)
+    _preload_torch_hip_runtime()
     L = ctypes.CDLL(path)
     vp = ctypes.c_void_p
     L.oc_abi_version.restype = ctypes.c_int

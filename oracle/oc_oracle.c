@@ -754,3 +754,26 @@ OC_EXPORT void oc_oracle_batch_reset(void **envs, int64_t n, const int32_t *mask
   for (int64_t i = 0; i < n; i++)
     if (!mask || mask[i]) env_reset((Env *)envs[i]);
 }
+
+/* K consecutive wrapper steps over envs [n0, n1) in one call (one call per thread in
+ * bench.py's cpu_baseline leg, so Python stays out of the timed loop).  actions is
+ * [K][4][n_stride]; only the last step's outputs are kept. */
+OC_EXPORT void oc_oracle_batch_multi_rollout(void **envs, int64_t n0, int64_t n1, int64_t n_stride,
+                                             int64_t K, const int32_t *actions, int32_t *comm,
+                                             int radius, int blind_mask, int C, int communication_on,
+                                             int ego_led, int ego_agent_idx, int can_move_mask,
+                                             int32_t *obs, double *timestep, double *reward,
+                                             int32_t *done, int auto_reset) {
+  for (int64_t k = 0; k < K; k++)
+    oc_oracle_batch_multi_step(envs, n0, n1, n_stride, actions + k * 4 * n_stride, comm, radius,
+                               blind_mask, C, communication_on, ego_led, ego_agent_idx, can_move_mask,
+                               obs, timestep, reward, done, auto_reset);
+}
+
+OC_EXPORT void oc_oracle_batch_rollout(void **envs, int64_t n0, int64_t n1, int64_t n_stride, int64_t K,
+                                       int A, const int32_t *actions, int32_t *reward, int32_t *done,
+                                       double *shaping, int auto_reset) {
+  for (int64_t k = 0; k < K; k++)
+    oc_oracle_batch_step(envs, n0, n1, n_stride, actions + k * A * n_stride, reward, done, shaping,
+                         auto_reset);
+}

@@ -56,6 +56,12 @@ def lib():
         L.oc_oracle_batch_multi_step.argtypes = (
             [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
              _I32P, _I32P] + [ctypes.c_int] * 7 + [_I32P, _F64P, _F64P, _I32P, ctypes.c_int])
+        L.oc_oracle_batch_multi_rollout.argtypes = (
+            [ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int64] * 4 + [_I32P, _I32P]
+            + [ctypes.c_int] * 7 + [_I32P, _F64P, _F64P, _I32P, ctypes.c_int])
+        L.oc_oracle_batch_rollout.argtypes = (
+            [ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int64] * 4 + [ctypes.c_int, _I32P, _I32P,
+                                                                         _I32P, _F64P, ctypes.c_int])
         L.oc_oracle_batch_snapshot.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64] + [_I32P] * 7
         L.oc_oracle_batch_reset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, _I32P]
         _lib = L
@@ -215,6 +221,38 @@ class OracleBatch:
             int(communication_on), int(ego_led), ego_agent_idx, can_move_mask, _p32(obs),
             _p64(ts), _p64(reward), _p32(done), int(auto_reset)))
         return obs, ts, reward, done
+
+    def multi_rollout(self, actions, comm, radius, blind_mask, C, communication_on=True,
+                      ego_led=False, ego_agent_idx=0, can_move_mask=3, auto_reset=True):
+        """K wrapper steps per call, actions [K][4][n]; each thread makes ONE C call."""
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        K = actions.shape[0]
+        assert actions.shape == (K, 4, self.n)
+        F = 22 + self.S + 2 * C
+        obs = np.zeros((2, F, self.n), np.int32)
+        ts = np.zeros(self.n, np.float64)
+        reward = np.zeros(self.n, np.float64)
+        done = np.zeros(self.n, np.int32)
+        L = lib()
+        self._run(lambda a, b: L.oc_oracle_batch_multi_rollout(
+            self._handles, a, b, self.n, K, _p32(actions), _p32(comm), radius, blind_mask, C,
+            int(communication_on), int(ego_led), ego_agent_idx, can_move_mask, _p32(obs),
+            _p64(ts), _p64(reward), _p32(done), int(auto_reset)))
+        return obs, ts, reward, done
+
+    def rollout(self, actions, auto_reset=True):
+        """K base-env steps per call, actions [K][A][n]."""
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        K = actions.shape[0]
+        assert actions.shape == (K, self.A, self.n)
+        reward = np.zeros(self.n, np.int32)
+        done = np.zeros(self.n, np.int32)
+        shaping = np.zeros((2, self.n), np.float64)
+        L = lib()
+        self._run(lambda a, b: L.oc_oracle_batch_rollout(
+            self._handles, a, b, self.n, K, self.A, _p32(actions), _p32(reward), _p32(done),
+            _p64(shaping), int(auto_reset)))
+        return reward, done, shaping
 
     def snapshot(self, i):
         e = OracleEnv.__new__(OracleEnv)
