@@ -293,9 +293,34 @@ def run_wrapper(name, level, T, steps, seed, kind="purpose", ego_agent_idx=0, **
     return out, int(np.sum(out["done"]))
 
 
+def run_ascii(level, A, T, script):
+    """str(env) (overcooked_environment.py:62-65) and holdings after every scripted step."""
+    env = H.base_env(H.make_arglist(level, A, T))
+    names = [a.name for a in env.sim_agents]
+    out = {"level": level, "num_agents": A, "T": T, "script": [list(s) for s in script],
+           "subtasks": [[st.name, list(st.args)] for st in env.all_subtasks],
+           "reset_str": str(env), "steps": []}
+    for acts in script:
+        acts = list(acts) + [4] * (A - len(acts))
+        with H.quiet():
+            r, d, info = env.step({n: NAV[a] for n, a in zip(names, acts)})
+        out["steps"].append({"str": str(env), "holding": [a.get_holding() for a in env.sim_agents],
+                             "locations": [list(a.location) for a in env.sim_agents],
+                             "termination_info": env.termination_info, "successful": env.successful,
+                             "reward": int(r), "done": bool(d)})
+    return out
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     summary = {}
+    asc = [run_ascii("open-divider_tomato", 2, 100, KAT1_TOMATO),
+           run_ascii("full-divider_salad", 2, 100, KAT2_SALAD)]
+    with open(os.path.join(HERE, "ascii_kat.json"), "w") as f:
+        json.dump(asc, f, indent=0)
+    print("ascii_kat.json", len(asc))
+    if "--ascii-only" in sys.argv:
+        return
 
     base_jobs = [
         # level, A, T, tapes
