@@ -178,7 +178,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
-        rollout_metrics = env.metrics.clone()           # before the probe launches below
+        rollout_metrics = env.metrics_vector()          # before the probe launches below
 
         # kernel duration for the roofline: HIP events on the launch stream around
         # individual launches (no graph), averaged

@@ -1,4 +1,4 @@
-"""ctypes loader for liboc_hip.so (include/oc_hip.h).
+"""ctypes loader for liboc_hip.so (include/oc_hip.h) and its per-level specialisations.
 
 There is no CPU fallback: if the library cannot be loaded, or a call fails, this
 raises.  (The CPU oracle under oracle/ is test infrastructure and is never used here.)
@@ -9,11 +9,11 @@ import os
 from . import build as _build
 
 _I32P = ctypes.POINTER(ctypes.c_int32)
-_I64P = ctypes.POINTER(ctypes.c_int64)
-_F64P = ctypes.POINTER(ctypes.c_double)
 
 SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destroy",
-           "oc_state_words", "oc_obs_rows", "oc_reset", "oc_step", "oc_obs", "oc_multi_step"]
+           "oc_level_spec_source", "oc_is_specialized",
+           "oc_metrics_slots", "oc_state_words", "oc_obs_rows", "oc_reset", "oc_step", "oc_obs",
+           "oc_multi_step"]
 
 
 class ObsCfg(ctypes.Structure):
@@ -31,7 +31,8 @@ class OcError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
+_hip_preloaded = False
 
 
 def _preload_torch_hip_runtime():
@@ -39,29 +40,26 @@ def _preload_torch_hip_runtime():
     Our library must bind to THAT runtime instance -- device pointers and streams come
     from torch -- so make sure it is the one already loaded when liboc_hip.so resolves
     its libamdhip64.so.7 dependency."""
+    global _hip_preloaded
+    if _hip_preloaded:
+        return
     import torch
     cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
     if os.path.exists(cand):
         ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    _hip_preloaded = True
 
 
-def load(path=None):
-    """Load (once) and type the library.  Raises if it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = path or os.environ.get("OC_HIP_LIB") or _build.LIB
-    if not os.path.exists(path):
-        raise OcError(
-            "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
-            " (there is no CPU fallback)" % path)
-    _preload_torch_hip_runtime()
-    L = ctypes.CDLL(path)
+def _declare(L):
     vp = ctypes.c_void_p
     L.oc_abi_version.restype = ctypes.c_int
+    L.oc_is_specialized.restype = ctypes.c_int
     L.oc_last_error.restype = ctypes.c_char_p
     L.oc_level_create.argtypes = [_I32P, ctypes.c_int32, ctypes.POINTER(vp)]
     L.oc_level_destroy.argtypes = [vp]
+    L.oc_level_spec_source.argtypes = [_I32P, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
+    L.oc_metrics_slots.argtypes = [ctypes.c_int64]
+    L.oc_metrics_slots.restype = ctypes.c_int64
     L.oc_state_words.argtypes = [vp]
     L.oc_state_words.restype = ctypes.c_int32
     L.oc_obs_rows.argtypes = [vp, ctypes.c_int32]
@@ -71,16 +69,31 @@ def load(path=None):
     L.oc_obs.argtypes = [vp, vp, vp, ctypes.POINTER(ObsCfg), vp, vp, ctypes.c_int64, vp]
     L.oc_multi_step.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
                                 ctypes.c_int32, vp, ctypes.c_int64, vp]
-    for f in ("oc_level_create", "oc_level_destroy", "oc_reset", "oc_step", "oc_obs",
-              "oc_multi_step"):
+    for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_reset", "oc_step",
+              "oc_obs", "oc_multi_step"):
         getattr(L, f).restype = ctypes.c_int
     if L.oc_abi_version() != 1:
         raise OcError("liboc_hip.so ABI version mismatch")
-    _lib = L
     return L
 
 
-def check(rc, what):
+def load(path=None):
+    """Load (once per path) and type a library.  Default: the generic liboc_hip.so."""
+    path = os.path.abspath(path or os.environ.get("OC_HIP_LIB") or _build.LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise OcError(
+            "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (there is no CPU fallback)" % path)
+    _preload_torch_hip_runtime()
+    L = _declare(ctypes.CDLL(path))
+    L._oc_path = path
+    _libs[path] = L
+    return L
+
+
+def check(rc, what, lib=None):
     if rc != 0:
-        msg = load().oc_last_error()
+        msg = (lib or load()).oc_last_error()
         raise OcError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

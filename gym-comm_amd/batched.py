@@ -15,7 +15,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import _lib, compiler
+from . import _lib, compiler, specialize
 from .state import unpack_state
 
 OBS_KEYS = ["object_encodings_x", "object_encodings_y", "state_encodings", "is_hidden",
@@ -38,7 +38,7 @@ class BatchedOvercooked:
                  ego_config=None, partner_config=None, num_communication=2,
                  communication_on=True, ego_led=False, fow_radius=2, ego_agent_idx=0,
                  device="cuda", subtask_order=None, placements=None, level_dir=None,
-                 max_num_subtasks=14, auto_reset=True, track_metrics=True):
+                 max_num_subtasks=14, auto_reset=True, track_metrics=True, specialize_level="auto"):
         cfg = {"ALLERGIC": False, "BLIND": False, "CAN_MOVE": True}   # missing CAN_MOVE = True
         self.ego_config = dict(cfg, **(ego_config or {}))
         self.partner_config = dict(cfg, **(partner_config or {}))
@@ -61,12 +61,13 @@ class BatchedOvercooked:
         self.A, self.M, self.S = lv.num_agents, lv.num_items, lv.num_subtasks
         self.C = int(num_communication)
         self.auto_reset = bool(auto_reset)
-        self._L = _lib.load()
+        blob = np.ascontiguousarray(lv.blob, dtype=np.int32)
+        # per-level specialised kernels when available (specialize.py), else the generic library
+        self.kernel_flavour, self._L = specialize.load_for(blob, specialize_level)
         with torch.cuda.device(self.device):
             h = ctypes.c_void_p()
-            blob = np.ascontiguousarray(lv.blob, dtype=np.int32)
             _lib.check(self._L.oc_level_create(blob.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                                               int(blob.size), ctypes.byref(h)), "oc_level_create")
+                                               int(blob.size), ctypes.byref(h)), "oc_level_create", self._L)
         self._h = h
         self.W_state = self._L.oc_state_words(h)
         self.F = self._L.oc_obs_rows(h, self.C)
@@ -80,7 +81,8 @@ class BatchedOvercooked:
         self.obs = torch.zeros((2, self.F, n), **i32)
         self.timestep = torch.zeros(n, dtype=torch.float64, device=self.device)
         self.shaped_reward = torch.zeros(n, dtype=torch.float64, device=self.device)
-        self.metrics = torch.zeros(8, dtype=torch.int64, device=self.device) if track_metrics else None
+        self.metrics = (torch.zeros((self._L.oc_metrics_slots(n), 8), dtype=torch.int64,
+                                    device=self.device) if track_metrics else None)
         self._obs_cfg = _lib.ObsCfg(int(fow_radius),
                                     (1 if self.ego_config["BLIND"] else 0) |
                                     (2 if self.partner_config["BLIND"] else 0), self.C, 0)
@@ -120,7 +122,7 @@ class BatchedOvercooked:
         if mask is not None:
             self._check_tensor(mask, (self.n,), torch.int32, "mask")
         _lib.check(self._L.oc_reset(self._h, self._p(self.state), self._p(mask), self.n,
-                                    self._stream()), "oc_reset")
+                                    self._stream()), "oc_reset", self._L)
 
     def step(self, actions: torch.Tensor, auto_reset: Optional[bool] = None):
         """Base-env step.  actions: int32 [A][n] action codes 0..4 (4 = stay).
@@ -130,7 +132,7 @@ class BatchedOvercooked:
         ar = self.auto_reset if auto_reset is None else auto_reset
         _lib.check(self._L.oc_step(self._h, self._p(self.state), self._p(actions),
                                    self._p(self.reward), self._p(self.done), self._p(self.shaping),
-                                   int(ar), self._p(self.metrics), self.n, self._stream()), "oc_step")
+                                   int(ar), self._p(self.metrics), self.n, self._stream()), "oc_step", self._L)
         return self.reward, self.done, self.shaping
 
     def observe(self):
@@ -138,7 +140,7 @@ class BatchedOvercooked:
         timestep f64 [n])."""
         _lib.check(self._L.oc_obs(self._h, self._p(self.state), self._p(self.comm),
                                   ctypes.byref(self._obs_cfg), self._p(self.obs),
-                                  self._p(self.timestep), self.n, self._stream()), "oc_obs")
+                                  self._p(self.timestep), self.n, self._stream()), "oc_obs", self._L)
         return self.obs, self.timestep
 
     def multi_step(self, actions: torch.Tensor, auto_reset: Optional[bool] = None):
@@ -150,7 +152,7 @@ class BatchedOvercooked:
             self._h, self._p(self.state), self._p(self.comm), self._p(actions),
             ctypes.byref(self._wrap_cfg), self._p(self.obs), self._p(self.timestep),
             self._p(self.shaped_reward), self._p(self.done), self._p(self.reward), int(ar),
-            self._p(self.metrics), self.n, self._stream()), "oc_multi_step")
+            self._p(self.metrics), self.n, self._stream()), "oc_multi_step", self._L)
         return self.obs, self.timestep, self.shaped_reward, self.done
 
     def obs_dict(self, viewer: int):
@@ -165,9 +167,13 @@ class BatchedOvercooked:
         """Named fields of every env's state (host numpy), see state.unpack_state."""
         return unpack_state(self.state.cpu().numpy(), self.A, self.M, self.S)
 
+    def metrics_vector(self):
+        """int64[8] totals (sum over the per-wave slots), on the device."""
+        return self.metrics.sum(dim=0)
+
     def read_metrics(self):
         if self.metrics is None:
             return None
-        m = self.metrics.cpu().tolist()
+        m = self.metrics_vector().cpu().tolist()
         return {"env_steps": m[0], "episodes": m[1], "successes": m[2], "reward_sum": m[3],
                 "completed_subtasks_sum": m[4], "errors": m[5]}

@@ -1,16 +1,30 @@
 // oc_kernels.hip -- hand-written CDNA4 (gfx950) kernels + the C ABI of liboc_hip.so.
 //
-// One lane = one environment.  The whole dynamic state of an env (A + M + 2 packed
-// int32 words, include/oc_hip.h) lives in VGPRs for the duration of a step; the
-// level's static tables (cell grid, path-distance table, subtask descriptors) are
-// staged once per workgroup into LDS.  All global tensors are env-major SoA, so each
-// wave load/store touches 256 contiguous bytes.  Pure integer / indexing work plus a
-// handful of fp64 divisions and adds for reward shaping: no MFMA.
+// One lane = one environment; the env's whole dynamic state (A + M + 2 packed int32
+// words, include/oc_hip.h) lives in VGPRs for the step.  All global tensors are
+// env-major SoA, so every wave load/store touches 256 contiguous bytes.
 //
-// Semantics follow the reference line by line (cited below, paths relative to the
-// reference root) but the data model is our own: objects are not heap nodes in a
-// dict of lists, they are equivalence classes over M base items, each item carrying
-// {cell, chopped, group, holder, world-order rank} in one register.
+// Everything that is the same for all envs of a launch (map bit-planes, subtask goal
+// sets, item types, lookup programs for reward shaping) travels BY VALUE in the kernel
+// argument block: it is read with scalar loads into SGPRs, costs no VGPRs, no LDS and
+// no workgroup barrier, and makes every test on it a scalar branch.  The only tables a
+// lane indexes with its own data -- the cell-to-cell path-distance table (u8) and the
+// table of fp64 quotients k / MAX_PATH -- are read straight from global memory (2.4 KB +
+// 2 KB, resident in every CU's vector L1 after first touch); the kernels were measured
+// with those tables staged in LDS first (round-1 "v1", profiles/r01_v1_*) and the
+// staging loop + barrier + LDS byte reads dominated the critical path at the BASELINE
+// batch sizes, where only 1-2 waves per SIMD exist to hide latency.
+//
+// Control flow inside a step is branch-free on per-lane data: interact() is a decision
+// phase (which of move / deliver / merge / chop / drop / pick fires) followed by
+// predicated per-item updates; done/reward use a bitmask of "which goal object exists"
+// instead of loops over subtasks.  Pure integer / indexing work; the fp64 shaping terms
+// are table lookups plus adds in the reference's order (bit-exact).  No MFMA.
+//
+// Semantics follow the reference line by line (citations = paths relative to the
+// reference root); the data model is our own: an Object is an equivalence class over M
+// base items, each item carrying {cell, chopped, group, holder, world-order rank,
+// type-set of its Object} in one register.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -22,29 +36,59 @@
 
 namespace {
 
-// ---------------------------------------------------------------------------
-// device-resident level image (copied verbatim into LDS by every workgroup)
-// ---------------------------------------------------------------------------
-struct DevLevel {
-  int32_t W, H, A, M, S, T, max_path, allergic, npair, ndeliv, ncells, image_words;
+constexpr int MAX_GOALS = 8;    // distinct goal type-sets
+constexpr int MAX_DELS = 4;     // Deliver subtasks
+constexpr int MAX_PAIRLK = 12;  // item-pair distance lookups of the shaping pair term
+constexpr int PLATE_BIT = 1 << OC_PLATE;
+
+// Uniform per-level data.  Generic build: passed by value in the kernel arguments
+// (scalar loads).  Specialised build (-DOC_SPECIALIZED, one .so per level, see
+// gym-comm_amd/specialize.py): a constexpr object, so every loop bound, type test and
+// bit-plane below folds at compile time and the kernels become straight-line code.
+struct LevelHdr {
+  int32_t W, H, ncells, max_path, S, A, M;
+  uint32_t item_types;   // nibble i = content type of item i
+  uint64_t nonfloor[2];  // bit c: cell c (= y*W + x) is not Floor
+  uint64_t cell_lo[2], cell_hi[2];  // cell type bit-planes
+  uint32_t nondeliver_mask, deliver_mask;  // subtask bitmasks by kind
+  uint32_t chop_mask[3];  // per food type: Chop(food) subtasks
+  uint32_t food_item[3];  // per food type: index of its item (255 = absent)
+  uint32_t ngoal;
+  uint32_t goal_tset[MAX_GOALS];  // distinct goal type-sets (bit t = type t present)
+  uint32_t goal_nd[MAX_GOALS];    // Chop/Merge subtasks whose goal is that set
+  uint32_t goal_dl[MAX_GOALS];    // Deliver subtasks whose goal is that set
+  uint32_t ndel;
+  uint32_t del_tset[MAX_DELS], del_bit[MAX_DELS];  // Deliver subtasks in subtask order
+  uint32_t npairlk;
+  uint32_t pairlk[MAX_PAIRLK];  // i | j<<4 | last_of_group<<8
+  uint32_t pair_static_max;     // name pairs with an absent type: each appends MAX_PATH
+  uint32_t ndeliv;
+  uint32_t deliv_pos[OC_MAX_DELIV];  // x | y<<4, world order
   int32_t init_words[OC_MAX_AGENTS + OC_MAX_ITEMS + 2];
-  uint16_t sub_sig[OC_MAX_SUBTASKS];
-  uint8_t sub_kind[OC_MAX_SUBTASKS];
-  int8_t sub_food[OC_MAX_SUBTASKS];
-  uint8_t cells[OC_MAX_CELLS];
-  uint8_t item_type[OC_MAX_ITEMS];
-  uint8_t pair_type[OC_MAX_PAIR];
-  uint8_t deliv_x[OC_MAX_DELIV], deliv_y[OC_MAX_DELIV];
-  // followed by ncells*ncells bytes: dist[a*ncells + b]
+  uint32_t nquot;  // entries in the quotient table
 };
-static_assert(sizeof(DevLevel) % 4 == 0, "DevLevel must be word sized");
+
+// per-run settings that do not select a specialisation
+struct RunCfg {
+  int32_t T;          // arglist.max_num_timesteps (0 = no limit)
+  uint32_t allergic;  // bit a: agent a is ALLERGIC
+};
+
+#ifdef OC_SPECIALIZED
+#include OC_SPEC_FILE  // constexpr LevelHdr OC_SPEC_HDR = {...};
+#define OC_HDR(p) OC_SPEC_HDR
+#else
+#define OC_HDR(p) (p).L
+#endif
 
 }  // namespace
 
 struct oc_level {
-  DevLevel host;
-  void *dev;          // device copy of DevLevel + dist
-  size_t image_bytes; // multiple of 4
+  LevelHdr hdr;
+  RunCfg run;
+  uint8_t *dev_dist;   // [ncells*ncells] u8
+  double *dev_quot;    // [nquot] (double)k / (double)max_path
+  int32_t *dev_init;   // init words (for k_reset)
   int device;
 };
 
@@ -66,8 +110,8 @@ int fail_hip(hipError_t e, const char *what) {
 // ---------------------------------------------------------------------------
 template <int A, int M>
 struct Env {
-  int ax[A], ay[A], ah[A];                               // ah: held group, -1 none
-  int ix[M], iy[M], ist[M], ig[M], iho[M], isq[M];       // iho: holder agent, -1 none
+  int ap[A], ah[A];                                   // agent cell (x | y<<4), held group (-1 none)
+  int ip[M], ist[M], ig[M], iho[M], isq[M], its[M];   // item cell, chopped, group, holder, rank, type-set
   int t, completed, goalcnt, mctr, err;
 };
 
@@ -75,19 +119,18 @@ template <int A, int M>
 __device__ __forceinline__ void unpack(Env<A, M> &e, const int32_t *w) {
 #pragma unroll
   for (int a = 0; a < A; a++) {
-    e.ax[a] = w[a] & 15;
-    e.ay[a] = (w[a] >> 4) & 15;
+    e.ap[a] = w[a] & 255;
     e.ah[a] = ((w[a] >> 8) & 15) - 1;
   }
 #pragma unroll
   for (int i = 0; i < M; i++) {
-    int v = w[A + i];
-    e.ix[i] = v & 15;
-    e.iy[i] = (v >> 4) & 15;
+    const int v = w[A + i];
+    e.ip[i] = v & 255;
     e.ist[i] = (v >> 8) & 1;
     e.ig[i] = (v >> 9) & 7;
     e.iho[i] = ((v >> 12) & 7) - 1;
     e.isq[i] = (v >> 16) & 255;
+    e.its[i] = (v >> 24) & 15;
   }
   e.t = w[A + M] & 0xFFFF;
   e.completed = (w[A + M] >> 16) & 0xFFFF;
@@ -99,189 +142,40 @@ __device__ __forceinline__ void unpack(Env<A, M> &e, const int32_t *w) {
 template <int A, int M>
 __device__ __forceinline__ void pack(const Env<A, M> &e, int32_t *w) {
 #pragma unroll
-  for (int a = 0; a < A; a++) w[a] = e.ax[a] | (e.ay[a] << 4) | ((e.ah[a] + 1) << 8);
+  for (int a = 0; a < A; a++) w[a] = e.ap[a] | ((e.ah[a] + 1) << 8);
 #pragma unroll
   for (int i = 0; i < M; i++)
-    w[A + i] = e.ix[i] | (e.iy[i] << 4) | (e.ist[i] << 8) | (e.ig[i] << 9) | ((e.iho[i] + 1) << 12) |
-               (e.isq[i] << 16);
+    w[A + i] = e.ip[i] | (e.ist[i] << 8) | (e.ig[i] << 9) | ((e.iho[i] + 1) << 12) | (e.isq[i] << 16) |
+               (e.its[i] << 24);
   w[A + M] = e.t | (e.completed << 16);
   w[A + M + 1] = e.goalcnt | (e.mctr << 16) | (e.err << 24);
 }
 
-// LDS view of the level
-struct Lv {
-  const DevLevel *h;
-  const uint8_t *dist;
-  int W, H, S, T, maxp, ncells;
-  __device__ __forceinline__ int cell(int x, int y) const { return h->cells[y * W + x]; }
-  __device__ __forceinline__ int D(int ax, int ay, int bx, int by) const {
-    return dist[(ay * W + ax) * ncells + (by * W + bx)];
-  }
-};
-
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Stage the level image into LDS (one copy per workgroup) and build the view.
-__device__ __forceinline__ Lv stage_level(const uint32_t *__restrict__ img, uint32_t *lds) {
-  const int words = uni((int)((const DevLevel *)img)->image_words);
-  for (int w = threadIdx.x; w < words; w += blockDim.x) lds[w] = img[w];
-  __syncthreads();
-  Lv lv;
-  lv.h = (const DevLevel *)lds;
-  lv.dist = (const uint8_t *)lds + sizeof(DevLevel);
-  lv.W = uni(lv.h->W);
-  lv.H = uni(lv.h->H);
-  lv.S = uni(lv.h->S);
-  lv.T = uni(lv.h->T);
-  lv.maxp = uni(lv.h->max_path);
-  lv.ncells = uni(lv.h->ncells);
-  return lv;
-}
-
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int px(int p) { return p & 15; }
+__device__ __forceinline__ int py(int p) { return p >> 4; }
+__device__ __forceinline__ int dense(const LevelHdr &L, int p) { return py(p) * L.W + px(p); }
+__device__ __forceinline__ int bit128(const uint64_t (&w)[2], int c) {
+  const uint64_t v = (c & 64) ? w[1] : w[0];
+  return (int)((v >> (c & 63)) & 1);
+}
+__device__ __forceinline__ int item_type(const LevelHdr &L, int i) { return (L.item_types >> (4 * i)) & 15; }
+__device__ __forceinline__ int manhattan(int p, int q) { return iabs(px(p) - px(q)) + iabs(py(p) - py(q)); }
 
 // ---------------------------------------------------------------------------
-// one environment tick
+// one environment tick: OvercookedEnvironment.step
+// (gym_cooking/envs/overcooked_environment.py:211-241)
 // ---------------------------------------------------------------------------
-// Per-object aggregates, indexed by item: signature (content-type counts, nibbles)
-// and "every food chopped" of the Object the item belongs to.
-template <int M>
-struct Agg {
-  int sig[M];
-  int chopped[M];
-};
-
 template <int A, int M>
-__device__ __forceinline__ void aggregate(const Env<A, M> &e, const int (&type)[M], Agg<M> &g) {
-#pragma unroll
-  for (int i = 0; i < M; i++) {
-    int s = 0, c = 1;
-#pragma unroll
-    for (int j = 0; j < M; j++) {
-      const bool same = e.ig[j] == e.ig[i];
-      s += same ? (1 << (4 * type[j])) : 0;
-      c &= (same && type[j] != OC_PLATE) ? e.ist[j] : 1;
-    }
-    g.sig[i] = s;
-    g.chopped[i] = c;
-  }
-}
-
-// reward_shaping for sim agents 0 and 1 together
-// (gym_cooking/envs/overcooked_environment.py:272-397).  Divisions are int/int in
-// Python = one correctly rounded fp64 division each; sums run left to right.
-template <int A, int M>
-__device__ __forceinline__ void shaping2(const Lv &lv, const Env<A, M> &e, const int (&type)[M],
-                                         const Agg<M> &g, double &s0, double &s1) {
-  const int MAXP = lv.maxp;
-  const double fmax = (double)MAXP;
-  const int npair = uni(lv.h->npair);
-  const int ndeliv = uni(lv.h->ndeliv);
-  constexpr int B = A < 2 ? A : 2;
-  double tot[2] = {0.0, 0.0};
-
-  // Chop term (:278-304): incomplete Chop(X) -> distance from the agent to the fresh X
-  int nchop = 0;
-  int mind[2] = {1 << 20, 1 << 20};
-  for (int s = 0; s < lv.S; s++) {
-    if (lv.h->sub_kind[s] != OC_CHOP || ((e.completed >> s) & 1)) continue;
-    const int food = lv.h->sub_food[s];
-    int fx = 0, fy = 0;
-#pragma unroll
-    for (int i = 0; i < M; i++)
-      if (type[i] == food) {
-        fx = e.ix[i];
-        fy = e.iy[i];
-      }
-#pragma unroll
-    for (int b = 0; b < B; b++) mind[b] = min(mind[b], lv.D(e.ax[b], e.ay[b], fx, fy));
-    nchop++;
-  }
-  const bool zero = nchop == 0;   // Python `total_penalty == 0` after the Chop term
-  if (nchop > 0) {
-#pragma unroll
-    for (int b = 0; b < B; b++)
-      tot[b] += (double)((mind[b] + MAXP) + (nchop - 1) * 2 * MAXP) / fmax;
-  }
-
-  // pair term (:319-363): agent independent
-  int npairs = 0, minpair = 1 << 20;
-  for (int p = 0; p < npair; p++)
-    for (int q = p + 1; q < npair; q++) {
-      const int tp = lv.h->pair_type[p], tq = lv.h->pair_type[q];
-      int m = MAXP;
-      bool hasp = false, hasq = false;
-#pragma unroll
-      for (int i = 0; i < M; i++) {
-        hasp |= type[i] == tp;
-        hasq |= type[i] == tq;
-        if (type[i] != tp) continue;
-#pragma unroll
-        for (int j = 0; j < M; j++)
-          if (type[j] == tq) m = min(m, lv.D(e.ix[i], e.iy[i], e.ix[j], e.iy[j]));
-      }
-      int val;
-      if (hasp && hasq) {
-        if (m == 0) continue;
-        val = m;
-      } else {
-        val = MAXP;
-      }
-      minpair = min(minpair, val);
-      npairs++;
-    }
-  if (npairs > 0) {
-    const double add = zero ? (double)(minpair + (npairs - 1) * MAXP) / fmax
-                            : (double)(npairs * MAXP) / fmax;
-#pragma unroll
-    for (int b = 0; b < B; b++) tot[b] += add;
-  }
-
-  // Deliver term (:370-395)
-  for (int s = 0; s < lv.S; s++) {
-    if (lv.h->sub_kind[s] != OC_DELIVER || ((e.completed >> s) & 1)) continue;
-    const int sig = lv.h->sub_sig[s];
-    bool match = false;
-    int mx = 0, my = 0;
-#pragma unroll
-    for (int i = 0; i < M; i++)
-      if (e.ig[i] == i && g.sig[i] == sig && g.chopped[i]) {
-        match = true;
-        mx = e.ix[i];
-        my = e.iy[i];
-      }
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-      if (!match) {
-        tot[b] += 2.0;
-      } else {
-        const int d = lv.D(e.ax[b], e.ay[b], mx, my) + iabs(e.ax[b] - mx) + iabs(e.ay[b] - my);
-        if (d == 0) {
-          int best = 1 << 20;
-          for (int k = 0; k < ndeliv; k++) {
-            const int dx = lv.h->deliv_x[k], dy = lv.h->deliv_y[k];
-            best = min(best, lv.D(e.ax[b], e.ay[b], dx, dy) + iabs(e.ax[b] - dx) + iabs(e.ay[b] - dy));
-          }
-          tot[b] += (double)best / fmax;
-        } else {
-          tot[b] += (double)d / fmax + 1.0;
-        }
-      }
-    }
-  }
-  s0 = tot[0];
-  s1 = B > 1 ? tot[1] : 0.0;
-}
-
-template <int A, int M>
-__device__ __forceinline__ void env_step(const Lv &lv, Env<A, M> &e, const int (&type)[M],
-                                         const int (&act_in)[A], int &reward, int &done,
-                                         int &success, double &s0, double &s1) {
-  const int W = lv.W, H = lv.H;
-  e.t += 1;                                            // overcooked_environment.py:213
+__device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
+                                         const double *__restrict__ quot, Env<A, M> &e,
+                                         const int (&act_in)[A], int &reward, int &done, int &success,
+                                         double &s0, double &s1) {
+  const int W = L.W, H = L.H;
+  e.t += 1;  // :213
 
   // ---- check_collisions (:578-613) on the ORIGINAL actions -------------------
-  int act[A], dx[A], dy[A], nx[A], ny[A];
+  int act[A], dx[A], dy[A], np[A];
 #pragma unroll
   for (int a = 0; a < A; a++) {
     int c = act_in[a];
@@ -289,12 +183,12 @@ __device__ __forceinline__ void env_step(const Lv &lv, Env<A, M> &e, const int (
     act[a] = c;
     dx[a] = (c == OC_ACT_RIGHT) - (c == OC_ACT_LEFT);
     dy[a] = (c == OC_ACT_DOWN) - (c == OC_ACT_UP);
-    const int px = e.ax[a] + dx[a], py = e.ay[a] + dy[a];
-    const bool inb = (unsigned)px < (unsigned)W && (unsigned)py < (unsigned)H;
-    if (!inb && A > 1) e.err |= OC_ERR_OOB;            // get_gridsquare_at asserts (world.py:310-315)
-    const bool blocked = !inb || lv.cell(inb ? px : e.ax[a], inb ? py : e.ay[a]) != OC_FLOOR;
-    nx[a] = blocked ? e.ax[a] : px;                    // :551-559
-    ny[a] = blocked ? e.ay[a] : py;
+    const int qx = px(e.ap[a]) + dx[a], qy = py(e.ap[a]) + dy[a];
+    const bool inb = (unsigned)qx < (unsigned)W && (unsigned)qy < (unsigned)H;
+    if (!inb) e.err |= OC_ERR_OOB;  // get_gridsquare_at asserts (utils/world.py:310-315)
+    const int qc = inb ? qy * W + qx : 0;
+    const bool blocked = !inb || bit128(L.nonfloor, qc);
+    np[a] = blocked ? e.ap[a] : (qx | (qy << 4));  // :551-559
   }
   bool ex[A];
 #pragma unroll
@@ -303,222 +197,307 @@ __device__ __forceinline__ void env_step(const Lv &lv, Env<A, M> &e, const int (
   for (int i = 0; i < A; i++)
 #pragma unroll
     for (int j = i + 1; j < A; j++) {
-      if (nx[i] == nx[j] && ny[i] == ny[j]) {          // :562-569
-        const bool i_stays = nx[i] == e.ax[i] && ny[i] == e.ay[i] && act[i] != OC_ACT_NOOP;
-        const bool j_stays = nx[j] == e.ax[j] && ny[j] == e.ay[j] && act[j] != OC_ACT_NOOP;
-        if (i_stays) {
-          ex[j] = false;
-        } else if (j_stays) {
-          ex[i] = false;
-        } else {
-          ex[i] = false;
-          ex[j] = false;
-        }
-      } else if (e.ax[i] == nx[j] && e.ay[i] == ny[j] && e.ax[j] == nx[i] && e.ay[j] == ny[i]) {
-        ex[i] = false;                                 // swap (:572-575)
-        ex[j] = false;
-      }
+      const bool same = np[i] == np[j];  // :562-569
+      const bool i_stays = np[i] == e.ap[i] && act[i] != OC_ACT_NOOP;
+      const bool j_stays = np[j] == e.ap[j] && act[j] != OC_ACT_NOOP;
+      const bool swap = e.ap[i] == np[j] && e.ap[j] == np[i];  // :572-575
+      const bool block_i = same ? !i_stays : swap;
+      const bool block_j = same ? (i_stays || !j_stays) : swap;
+      ex[i] = ex[i] && !block_i;
+      ex[j] = ex[j] && !block_j;
     }
 
   // ---- execute_navigation (:615-618): interact(), sequential in agent order ---
-  const int allergic = uni(lv.h->allergic);
+  // decision phase + predicated per-item updates (utils/interact.py:4-75)
 #pragma unroll
   for (int a = 0; a < A; a++) {
-    if (!ex[a] || act[a] == OC_ACT_NOOP) continue;     // blocked -> (0,0) (:610-612); interact.py:12
-    const int tx = min(max(e.ax[a] + dx[a], 0), W - 1);  // world.inbounds (world.py:317-320)
-    const int ty = min(max(e.ay[a] + dy[a], 0), H - 1);
-    const int c = lv.cell(tx, ty);
-    if (c == OC_FLOOR) {                               // interact.py:19-20, agent.py:311-314
-      e.ax[a] = tx;
-      e.ay[a] = ty;
+    const bool acting = ex[a] && act[a] != OC_ACT_NOOP;  // blocked -> (0,0) (:610-612); interact.py:12
+    const int pa = e.ap[a];
+    const int tx = min(max(px(pa) + dx[a], 0), W - 1);   // world.inbounds (world.py:317-320)
+    const int ty = min(max(py(pa) + dy[a], 0), H - 1);
+    const int tp = tx | (ty << 4);
+    const int tc = ty * W + tx;
+    const int ct = bit128(L.cell_lo, tc) | (bit128(L.cell_hi, tc) << 1);
+    const bool holding = e.ah[a] >= 0;
+    // the held Object (items with holder == a) and the unheld Object on the target cell
+    int held_n = 0, held_ts = 0, held_fresh = 0, held_seq = 0;
+    int tgt_any = 0, tgt_ts = 0, tgt_fresh = 0, og = 7;
+    bool mine[M], tgt[M];
 #pragma unroll
-      for (int i = 0; i < M; i++)
-        if (e.iho[i] == a) {
-          e.ix[i] = tx;
-          e.iy[i] = ty;
-        }
-    } else if (e.ah[a] >= 0) {                         // holding (:23)
-      const int g = e.ah[a];
-      int n = 0, plates = 0, chopped = 1, lone_fresh_food = 0;
-#pragma unroll
-      for (int i = 0; i < M; i++)
-        if (e.ig[i] == g) {
-          n++;
-          if (type[i] == OC_PLATE) {
-            plates++;
-          } else {
-            chopped &= e.ist[i];
-            lone_fresh_food = !e.ist[i];
-          }
-        }
-      if (c == OC_DELIVERY) {                          // :25-30, is_deliverable core.py:232-237
-        if (n > 1 && chopped) {
-#pragma unroll
-          for (int i = 0; i < M; i++)
-            if (e.ig[i] == g) {
-              e.ix[i] = tx;
-              e.iy[i] = ty;
-              e.iho[i] = -1;
-            }
-          e.ah[a] = -1;
-        }
-      } else {
-        int og = -1;                                   // unheld Object on the target cell
-#pragma unroll
-        for (int i = 0; i < M; i++)
-          if (og < 0 && e.iho[i] < 0 && e.ix[i] == tx && e.iy[i] == ty) og = e.ig[i];
-        if (og >= 0) {                                 // :33-46
-#pragma unroll
-          for (int i = 0; i < M; i++)
-            if (e.ig[i] == og) {
-              if (type[i] == OC_PLATE)
-                plates++;
-              else
-                chopped &= e.ist[i];
-            }
-          if (plates <= 1 && chopped) {                // mergeable (core.py:240-257)
-            if (A > 2) {
-              // World.remove(agent.holding) deletes by (name, location), last match
-              // (world.py:239-247): with a second agent on the same cell holding a
-              // same-named Object that sits later in world order it removes the wrong
-              // one and the reference's store is corrupt from here on.  Flag it.
-              int my_sig = 0, my_seq = 0;
-#pragma unroll
-              for (int i = 0; i < M; i++)
-                if (e.ig[i] == g) {
-                  my_sig += 1 << (4 * type[i]);
-                  my_seq = e.isq[i];
-                }
-#pragma unroll
-              for (int j = 0; j < M; j++) {
-                if (e.ig[j] == g || e.iho[j] < 0 || e.ig[j] != j) continue;
-                if (e.ix[j] != e.ax[a] || e.iy[j] != e.ay[a]) continue;
-                int sj = 0;
-#pragma unroll
-                for (int k = 0; k < M; k++)
-                  if (e.ig[k] == j) sj += 1 << (4 * type[k]);
-                if (sj == my_sig && e.isq[j] > my_seq) e.err |= OC_ERR_ALIAS;
-              }
-            }
-            const int newg = min(g, og);
-            const int seq = M + e.mctr;                // re-inserted under a new name: last in world order
-            e.mctr += 1;
-#pragma unroll
-            for (int i = 0; i < M; i++)
-              if (e.ig[i] == g || e.ig[i] == og) {
-                e.ig[i] = newg;
-                e.ix[i] = e.ax[a];
-                e.iy[i] = e.ay[a];
-                e.iho[i] = a;
-                e.isq[i] = seq;
-              }
-            e.ah[a] = newg;
-          }
-        } else if (c == OC_CUTBOARD && n == 1 && lone_fresh_food) {   // :52-54 chop in hand
-#pragma unroll
-          for (int i = 0; i < M; i++)
-            if (e.ig[i] == g) e.ist[i] = 1;
-        } else {                                       // :56-57 put down
-#pragma unroll
-          for (int i = 0; i < M; i++)
-            if (e.ig[i] == g) {
-              e.ix[i] = tx;
-              e.iy[i] = ty;
-              e.iho[i] = -1;
-            }
-          e.ah[a] = -1;
-        }
-      }
-    } else if (c != OC_DELIVERY) {                     // empty hands (:62-71)
-      int og = -1;
-#pragma unroll
-      for (int i = 0; i < M; i++)
-        if (og < 0 && e.iho[i] < 0 && e.ix[i] == tx && e.iy[i] == ty) og = e.ig[i];
-      if (og >= 0 && !((allergic >> a) & 1)) {         // ALLERGIC: acquire is a no-op (agent.py:296-298)
-#pragma unroll
-        for (int i = 0; i < M; i++)
-          if (e.ig[i] == og) {
-            e.iho[i] = a;
-            e.ix[i] = e.ax[a];
-            e.iy[i] = e.ay[a];
-          }
-        e.ah[a] = og;
-      }
+    for (int i = 0; i < M; i++) {
+      const int food_fresh = (item_type(L, i) != OC_PLATE) & (e.ist[i] ^ 1);
+      mine[i] = e.iho[i] == a;
+      tgt[i] = e.iho[i] < 0 && e.ip[i] == tp;
+      held_n += mine[i];
+      held_ts |= mine[i] ? e.its[i] : 0;
+      held_fresh |= mine[i] ? food_fresh : 0;
+      held_seq = mine[i] ? e.isq[i] : held_seq;
+      tgt_any |= tgt[i];
+      tgt_ts |= tgt[i] ? e.its[i] : 0;
+      tgt_fresh |= tgt[i] ? food_fresh : 0;
+      og = tgt[i] ? min(og, e.ig[i]) : og;
     }
+    const bool nf = acting && ct != OC_FLOOR;
+    const bool do_move = acting && ct == OC_FLOOR;                       // interact.py:19-20
+    const bool at_deliv = ct == OC_DELIVERY;
+    const bool do_deliver = nf && holding && at_deliv && held_n > 1 && !held_fresh;   // :25-30, core.py:232-237
+    const bool mergeable = !((held_ts & tgt_ts) & PLATE_BIT) && !held_fresh && !tgt_fresh;  // core.py:240-257
+    const bool do_merge = nf && holding && !at_deliv && tgt_any && mergeable;         // :33-46
+    const bool chop_here = ct == OC_CUTBOARD && held_n == 1 && held_fresh;            // :52
+    const bool do_chop = nf && holding && !at_deliv && !tgt_any && chop_here;         // :52-54
+    const bool do_drop = nf && holding && !at_deliv && !tgt_any && !chop_here;        // :56-57
+    const bool do_pick = nf && !holding && !at_deliv && tgt_any && !((R.allergic >> a) & 1);  // :62-71, agent.py:296-298
+    const bool put = do_deliver || do_drop;
+    const bool take = do_merge || do_pick;
+    const int newg = min(e.ah[a] < 0 ? 7 : e.ah[a], og);
+    const int newseq = M + e.mctr;  // re-inserted under a new name: last in world order (world.py:236-237)
+    const int merged_ts = held_ts | tgt_ts;
+    if (A > 2) {
+      // World.remove(agent.holding) deletes by (name, location), last match
+      // (world.py:239-247): with another agent on the same cell holding a same-named
+      // Object that sits later in world order it removes the wrong one and the
+      // reference's store is corrupt from here on.  Flag it.
+      bool alias = false;
+#pragma unroll
+      for (int j = 0; j < M; j++)
+        alias |= e.iho[j] >= 0 && e.iho[j] != a && e.ip[j] == pa && e.its[j] == held_ts && e.isq[j] > held_seq;
+      if (do_merge && alias) e.err |= OC_ERR_ALIAS;
+    }
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+      const bool both = do_merge && (mine[i] || tgt[i]);
+      e.ip[i] = (mine[i] && (do_move || put)) ? tp : ((tgt[i] && take) ? pa : e.ip[i]);
+      e.iho[i] = (mine[i] && put) ? -1 : ((tgt[i] && take) ? a : e.iho[i]);
+      e.ig[i] = both ? newg : e.ig[i];
+      e.isq[i] = both ? newseq : e.isq[i];
+      e.its[i] = both ? merged_ts : e.its[i];
+      e.ist[i] = (do_chop && mine[i]) ? 1 : e.ist[i];
+    }
+    e.ap[a] = do_move ? tp : pa;  // agent.py:311-314
+    e.ah[a] = put ? -1 : (take ? newg : e.ah[a]);
+    e.mctr += do_merge ? 1 : 0;
   }
 
   // ---- done (:243-270) and reward (:399-432) ---------------------------------
-  Agg<M> g;
-  aggregate<A, M>(e, type, g);
-  const int d0x = uni(lv.h->deliv_x[0]), d0y = uni(lv.h->deliv_y[0]);  // first Delivery tile only (:259,:402)
-  bool all_delivered = true;
-  int r = 0;
-  for (int s = 0; s < lv.S; s++) {
-    const int kind = lv.h->sub_kind[s];
-    const int sig = lv.h->sub_sig[s];
-    bool match = false, on_delivery = false;
+  // present / at_delivery: bit s set iff an Object with type-set s and every food chopped
+  // exists (anywhere / on the first Delivery tile).  A multi-item Object is all-chopped
+  // by construction (mergeable() required it).
+  const int d0 = (int)L.deliv_pos[0];  // first Delivery tile only (:259,:402)
+  int present = 0, at_delivery = 0;
 #pragma unroll
-    for (int i = 0; i < M; i++)
-      if (e.ig[i] == i && g.sig[i] == sig && g.chopped[i]) {
-        match = true;
-        on_delivery |= e.ix[i] == d0x && e.iy[i] == d0y;
-      }
-    if (kind == OC_DELIVER) {
-      all_delivered &= on_delivery;
-      if (on_delivery) {
-        r += 3;
-        e.completed |= 1 << s;
-      }
-    } else {
-      const int cnt = match ? 1 : 0;                   // #distinct cells holding the goal object
-      if (cnt > ((e.goalcnt >> s) & 1)) {
-        r += 1;
-        e.completed |= 1 << s;
-      }
-      e.goalcnt = (e.goalcnt & ~(1 << s)) | (cnt << s);
+  for (int i = 0; i < M; i++) {
+    const int tb = 1 << item_type(L, i);
+    const bool ok = e.ig[i] == i && (e.its[i] != tb || item_type(L, i) == OC_PLATE || e.ist[i]);
+    const int b = ok ? (1 << e.its[i]) : 0;
+    present |= b;
+    at_delivery |= (e.ip[i] == d0) ? b : 0;
+  }
+  int cnt_mask = 0, del_mask = 0;
+#pragma unroll
+  for (int g = 0; g < MAX_GOALS; g++) {
+    if (g < (int)L.ngoal) {  // uniform
+      const bool has = (present >> L.goal_tset[g]) & 1;
+      const bool hasd = (at_delivery >> L.goal_tset[g]) & 1;
+      cnt_mask |= has ? (int)L.goal_nd[g] : 0;
+      del_mask |= hasd ? (int)L.goal_dl[g] : 0;
     }
   }
-  const bool timeout = lv.T != 0 && e.t >= lv.T;       // checked first (:245-249)
+  const int newly = cnt_mask & ~e.goalcnt;  // goal count rose above goal_objects_count (:408-415)
+  reward = __popc(newly) + 3 * __popc(del_mask);  // Deliver pays +3 every step (:400-406)
+  e.completed |= newly | del_mask;
+  e.goalcnt = cnt_mask;
+  const bool timeout = R.T != 0 && e.t >= R.T;  // checked first (:245-249)
+  const bool all_delivered = del_mask == (int)L.deliver_mask;
   done = (timeout || all_delivered) ? 1 : 0;
   success = (!timeout && all_delivered) ? 1 : 0;
-  reward = r;
-  shaping2<A, M>(lv, e, type, g, s0, s1);              // after reward(): uses the updated completed flags
+
+  // ---- calculate_reward_shaping for sim agents 0 and 1 (:272-397) ------------
+  // int/int divisions of the reference = entries of the quotient table k / MAX_PATH;
+  // sums run left to right in fp64.
+  const int MAXP = L.max_path;
+  const int nc = L.ncells;
+  constexpr int B = A < 2 ? A : 2;
+  int arow[B];
+#pragma unroll
+  for (int b = 0; b < B; b++) arow[b] = dense(L, e.ap[b]) * nc;
+  int ic[M];
+#pragma unroll
+  for (int i = 0; i < M; i++) ic[i] = dense(L, e.ip[i]);
+
+  // issue every distance lookup first, consume afterwards
+  int d_chop[3][B];
+#pragma unroll
+  for (int f = 0; f < 3; f++) {
+#pragma unroll
+    for (int b = 0; b < B; b++) d_chop[f][b] = 0;
+    if (L.chop_mask[f] != 0) {  // uniform
+      int fc = 0;
+#pragma unroll
+      for (int i = 0; i < M; i++) fc = ((int)L.food_item[f] == i) ? ic[i] : fc;
+#pragma unroll
+      for (int b = 0; b < B; b++) d_chop[f][b] = dist[arow[b] + fc];
+    }
+  }
+  int d_pair[MAX_PAIRLK];
+#pragma unroll
+  for (int k = 0; k < MAX_PAIRLK; k++) {
+    d_pair[k] = 0;
+    if (k < (int)L.npairlk) {  // uniform
+      const int li = L.pairlk[k] & 15, lj = (L.pairlk[k] >> 4) & 15;
+      int ci = 0, cj = 0;
+#pragma unroll
+      for (int i = 0; i < M; i++) {
+        ci = (li == i) ? ic[i] : ci;
+        cj = (lj == i) ? ic[i] : cj;
+      }
+      d_pair[k] = dist[ci * nc + cj];
+    }
+  }
+  int del_has[MAX_DELS], del_p[MAX_DELS], d_del[MAX_DELS][B];
+#pragma unroll
+  for (int k = 0; k < MAX_DELS; k++) {
+    del_has[k] = 0;
+    del_p[k] = 0;
+#pragma unroll
+    for (int b = 0; b < B; b++) d_del[k][b] = 0;
+    if (k < (int)L.ndel) {  // uniform
+      int mc = 0;
+#pragma unroll
+      for (int i = 0; i < M; i++) {
+        const int tb = 1 << item_type(L, i);
+        const bool ok = e.ig[i] == i && e.its[i] == (int)L.del_tset[k] &&
+                        (e.its[i] != tb || item_type(L, i) == OC_PLATE || e.ist[i]);
+        del_has[k] |= ok;
+        del_p[k] = ok ? e.ip[i] : del_p[k];
+        mc = ok ? ic[i] : mc;
+      }
+#pragma unroll
+      for (int b = 0; b < B; b++) d_del[k][b] = dist[arow[b] + mc];
+    }
+  }
+  int d_tile[B];  // min over Delivery tiles of path distance + manhattan (:382-388)
+#pragma unroll
+  for (int b = 0; b < B; b++) d_tile[b] = 1 << 20;
+#pragma unroll
+  for (int k = 0; k < OC_MAX_DELIV; k++)
+    if (k < (int)L.ndeliv) {  // uniform
+      const int dp = (int)L.deliv_pos[k];
+      const int dc = dense(L, dp);
+#pragma unroll
+      for (int b = 0; b < B; b++) d_tile[b] = min(d_tile[b], (int)dist[arow[b] + dc] + manhattan(e.ap[b], dp));
+    }
+
+  // Chop term (:278-304)
+  int nchop = 0;
+  int mind[B];
+#pragma unroll
+  for (int b = 0; b < B; b++) mind[b] = 1 << 20;
+#pragma unroll
+  for (int f = 0; f < 3; f++)
+    if (L.chop_mask[f] != 0) {  // uniform
+      const int open = __popc((int)L.chop_mask[f] & ~e.completed);
+      nchop += open;
+#pragma unroll
+      for (int b = 0; b < B; b++) mind[b] = open ? min(mind[b], d_chop[f][b]) : mind[b];
+    }
+  // pair term (:319-363): agent independent
+  int npairs = (int)L.pair_static_max;
+  int minpair = npairs ? MAXP : (1 << 20);
+  {
+    int cur = MAXP;
+#pragma unroll
+    for (int k = 0; k < MAX_PAIRLK; k++)
+      if (k < (int)L.npairlk) {  // uniform
+        cur = min(cur, d_pair[k]);
+        if ((L.pairlk[k] >> 8) & 1) {  // uniform: last lookup of this name pair
+          const bool keep = cur != 0;    // a zero distance is not appended (:351-352)
+          npairs += keep ? 1 : 0;
+          minpair = keep ? min(minpair, cur) : minpair;
+          cur = MAXP;
+        }
+      }
+  }
+  // the quotients
+  int kq_chop[B], kq_pair;
+#pragma unroll
+  for (int b = 0; b < B; b++) kq_chop[b] = nchop ? (mind[b] + MAXP) + (nchop - 1) * 2 * MAXP : 0;
+  kq_pair = nchop ? npairs * MAXP : (npairs ? minpair + (npairs - 1) * MAXP : 0);
+  int kq_del[MAX_DELS][B];
+  bool del_direct[MAX_DELS][B];
+#pragma unroll
+  for (int k = 0; k < MAX_DELS; k++)
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      kq_del[k][b] = 0;
+      del_direct[k][b] = false;
+      if (k < (int)L.ndel) {
+        const int d = d_del[k][b] + manhattan(e.ap[b], del_p[k]);
+        del_direct[k][b] = d == 0;                 // the agent holds it (:381)
+        kq_del[k][b] = d == 0 ? d_tile[b] : d;
+      }
+    }
+  const int qmax = (int)L.nquot - 1;
+  double q_chop[B], q_pair, q_del[MAX_DELS][B];
+#pragma unroll
+  for (int b = 0; b < B; b++) q_chop[b] = quot[min(kq_chop[b], qmax)];
+  q_pair = quot[min(kq_pair, qmax)];
+#pragma unroll
+  for (int k = 0; k < MAX_DELS; k++)
+#pragma unroll
+    for (int b = 0; b < B; b++) q_del[k][b] = (k < (int)L.ndel) ? quot[min(kq_del[k][b], qmax)] : 0.0;
+
+  double tot[B];
+#pragma unroll
+  for (int b = 0; b < B; b++) {
+    tot[b] = 0.0;
+    if (nchop) tot[b] += q_chop[b];
+    if (npairs) tot[b] += q_pair;
+  }
+#pragma unroll
+  for (int k = 0; k < MAX_DELS; k++)
+    if (k < (int)L.ndel) {  // uniform; Deliver term in subtask order (:370-395)
+      const bool open = !((e.completed >> L.del_bit[k]) & 1);
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const double add = !del_has[k] ? 2.0 : (del_direct[k][b] ? q_del[k][b] : q_del[k][b] + 1.0);
+        tot[b] = open ? tot[b] + add : tot[b];
+      }
+    }
+  s0 = tot[0];
+  s1 = B > 1 ? tot[1] : 0.0;
 }
 
 // get_observation2 (gym_comm/envs/overcooked_env.py:105-159) for one viewer;
 // writes F = 22 + S + 2C rows with stride n.
 template <int A, int M>
-__device__ __forceinline__ void env_obs(const Lv &lv, const Env<A, M> &e, const int (&type)[M],
-                                        int viewer, int radius, bool viewer_blind, bool ego_blind,
-                                        int C, int comm0, int comm1, int32_t *__restrict__ out,
-                                        int64_t n) {
-  const int vx = viewer == 0 ? e.ax[0] : e.ax[1];
-  const int vy = viewer == 0 ? e.ay[0] : e.ay[1];
+__device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, int viewer, int radius,
+                                        bool viewer_blind, bool ego_blind, int C, int comm0, int comm1,
+                                        int32_t *__restrict__ out, int64_t n) {
+  const int vp = viewer == 0 ? e.ap[0] : e.ap[1];
   const int vh = viewer == 0 ? e.ah[0] : e.ah[1];
+  const int vx = px(vp), vy = py(vp);
   int ddx[4], ddy[4], st[4], hid[4];
 #pragma unroll
   for (int ch = 0; ch < 4; ch++) {
     // last writer in world.objects order wins (:121-131): the item of this type
     // whose Object has the highest rank
-    int best = -1, bx = 0, by = 0, bs = 0;
+    int best = -1, bp = 0, bs = 0;
 #pragma unroll
     for (int i = 0; i < M; i++)
-      if (type[i] == ch && e.isq[i] > best) {
-        best = e.isq[i];
-        bx = e.ix[i] - vx;
-        by = e.iy[i] - vy;
-        bs = ch == OC_PLATE ? 0 : e.ist[i];
+      if (item_type(L, i) == ch) {  // uniform
+        const bool better = e.isq[i] > best;
+        best = better ? e.isq[i] : best;
+        bp = better ? e.ip[i] : bp;
+        bs = better ? e.ist[i] : bs;
       }
     const bool have = best >= 0 && !viewer_blind;
-    ddx[ch] = have ? bx : 0;
-    ddy[ch] = have ? by : 0;
-    st[ch] = have ? bs : 0;
+    ddx[ch] = have ? px(bp) - vx : 0;
+    ddy[ch] = have ? py(bp) - vy : 0;
+    st[ch] = (have && ch != OC_PLATE) ? bs : 0;
     const bool within = iabs(ddx[ch]) + iabs(ddy[ch]) <= radius;
-    hid[ch] = viewer_blind ? 1 : (within ? 0 : 1);     // :109,:133
-    if (within) {                                      // :135 (sic: zeroed when visible)
-      ddx[ch] = 0;
-      ddy[ch] = 0;
-    }
+    hid[ch] = viewer_blind ? 1 : (within ? 0 : 1);  // :109,:133
+    ddx[ch] = within ? 0 : ddx[ch];                 // :135 (sic: zeroed when visible)
+    ddy[ch] = within ? 0 : ddy[ch];
   }
   int row = 0;
 #pragma unroll
@@ -529,11 +508,11 @@ __device__ __forceinline__ void env_obs(const Lv &lv, const Env<A, M> &e, const 
   for (int ch = 0; ch < 4; ch++) out[(row++) * n] = st[ch];
 #pragma unroll
   for (int ch = 0; ch < 4; ch++) out[(row++) * n] = hid[ch];
-  for (int s = 0; s < lv.S; s++) out[(row++) * n] = (e.completed >> s) & 1;
-  out[(row++) * n] = viewer_blind ? 0 : e.ax[0];       // :139-143
-  out[(row++) * n] = viewer_blind ? 0 : e.ay[0];
-  out[(row++) * n] = viewer_blind ? 0 : e.ax[1];
-  out[(row++) * n] = viewer_blind ? 0 : e.ay[1];
+  for (int s = 0; s < L.S; s++) out[(row++) * n] = (e.completed >> s) & 1;
+  out[(row++) * n] = viewer_blind ? 0 : px(e.ap[0]);  // :139-143
+  out[(row++) * n] = viewer_blind ? 0 : py(e.ap[0]);
+  out[(row++) * n] = viewer_blind ? 0 : px(e.ap[1]);
+  out[(row++) * n] = viewer_blind ? 0 : py(e.ap[1]);
   out[(row++) * n] = ego_blind ? 0 : (vh >= 0 ? 1 : 0);  // :154, gated on the EGO's BLIND flag
   out[(row++) * n] = 0;
   for (int c = 0; c < C; c++) out[(row++) * n] = comm0 == c ? 1 : 0;
@@ -541,15 +520,18 @@ __device__ __forceinline__ void env_obs(const Lv &lv, const Env<A, M> &e, const 
 }
 
 // wave-level metric accumulation: ballot/popcount for the flags, a butterfly sum for
-// the integers, then one atomic per wave.
+// the integers, then lane 0 adds them into the wave's OWN 64-byte slot of the metrics
+// tensor (int64 [ceil(n/64)][8]).  No atomics: round-1 v1 used one device-wide counter
+// set and its 2 048 same-address atomics per launch (~11 ns each) were 60 % of the
+// n = 131 072 launch.  Launches that share a metrics tensor are ordered by the stream.
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
-__device__ __forceinline__ void accumulate_metrics(int64_t *metrics, bool valid, int done, int success,
-                                                   int reward, int completed_bits, bool err) {
+__device__ __forceinline__ void accumulate_metrics(int64_t *metrics, int64_t env_index, bool valid, int done,
+                                                   int success, int reward, int completed_bits, bool err) {
   if (metrics == nullptr) return;
   const unsigned long long vmask = __ballot(valid);
   const unsigned long long dmask = __ballot(valid && done);
@@ -557,28 +539,25 @@ __device__ __forceinline__ void accumulate_metrics(int64_t *metrics, bool valid,
   const unsigned long long emask = __ballot(valid && err);
   const int rsum = wave_sum(valid ? reward : 0);
   const int csum = wave_sum((valid && done) ? __popc(completed_bits) : 0);
-  if ((threadIdx.x & 63) == 0) {
-    unsigned long long *m = (unsigned long long *)metrics;
-    if (vmask) atomicAdd(&m[OC_MET_ENV_STEPS], (unsigned long long)__popcll(vmask));
-    if (dmask) atomicAdd(&m[OC_MET_EPISODES], (unsigned long long)__popcll(dmask));
-    if (smask) atomicAdd(&m[OC_MET_SUCCESSES], (unsigned long long)__popcll(smask));
-    if (rsum) atomicAdd(&m[OC_MET_REWARD_SUM], (unsigned long long)(long long)rsum);
-    if (csum) atomicAdd(&m[OC_MET_COMPLETED_SUM], (unsigned long long)(long long)csum);
-    if (emask) atomicAdd(&m[OC_MET_ERRORS], (unsigned long long)__popcll(emask));
+  if ((threadIdx.x & 63) == 0 && vmask) {
+    int64_t *m = metrics + (env_index >> 6) * OC_MET_COUNT;
+    m[OC_MET_ENV_STEPS] += __popcll(vmask);
+    if (dmask) m[OC_MET_EPISODES] += __popcll(dmask);
+    if (smask) m[OC_MET_SUCCESSES] += __popcll(smask);
+    if (rsum) m[OC_MET_REWARD_SUM] += rsum;
+    if (csum) m[OC_MET_COMPLETED_SUM] += csum;
+    if (emask) m[OC_MET_ERRORS] += __popcll(emask);
   }
 }
 
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int M>
-__device__ __forceinline__ void load_types(const Lv &lv, int (&type)[M]) {
-#pragma unroll
-  for (int i = 0; i < M; i++) type[i] = uni(lv.h->item_type[i]);
-}
-
 struct StepArgs {
-  const uint32_t *level;
+  LevelHdr L;
+  RunCfg R;
+  const uint8_t *dist;
+  const double *quot;
   int32_t *state;
   const int32_t *actions;
   int32_t *reward;
@@ -590,28 +569,25 @@ struct StepArgs {
 };
 
 template <int A, int M>
-__global__ void __launch_bounds__(256) k_step(StepArgs p) {
-  extern __shared__ uint32_t lds[];
-  const Lv lv = stage_level(p.level, lds);
+__global__ void __launch_bounds__(256) k_step(const StepArgs p) {
+  const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < p.n;
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
     constexpr int WS = A + M + 2;
-    int type[M];
-    load_types<M>(lv, type);
     int32_t w[WS];
 #pragma unroll
     for (int r = 0; r < WS; r++) w[r] = p.state[(int64_t)r * p.n + i];
-    Env<A, M> e;
-    unpack<A, M>(e, w);
     int act[A];
 #pragma unroll
     for (int a = 0; a < A; a++) act[a] = p.actions[(int64_t)a * p.n + i];
+    Env<A, M> e;
+    unpack<A, M>(e, w);
     const int err_before = e.err;
     double s0, s1;
-    env_step<A, M>(lv, e, type, act, reward, done, success, s0, s1);
+    env_step<A, M>(L, p.R, p.dist, p.quot, e, act, reward, done, success, s0, s1);
     comp = e.completed;
     err = e.err != err_before;
     p.reward[i] = reward;
@@ -620,18 +596,19 @@ __global__ void __launch_bounds__(256) k_step(StepArgs p) {
     p.shaping[p.n + i] = s1;
     if (done && p.auto_reset) {
 #pragma unroll
-      for (int r = 0; r < WS; r++) w[r] = lv.h->init_words[r];
+      for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
     } else {
       pack<A, M>(e, w);
     }
 #pragma unroll
     for (int r = 0; r < WS; r++) p.state[(int64_t)r * p.n + i] = w[r];
   }
-  accumulate_metrics(p.metrics, valid, done, success, reward, comp, err);
+  accumulate_metrics(p.metrics, i, valid, done, success, reward, comp, err);
 }
 
 struct ObsArgs {
-  const uint32_t *level;
+  LevelHdr L;
+  RunCfg R;
   const int32_t *state;
   const int32_t *comm;
   int32_t *obs;
@@ -641,48 +618,47 @@ struct ObsArgs {
 };
 
 template <int A, int M>
-__global__ void __launch_bounds__(256) k_obs(ObsArgs p) {
-  extern __shared__ uint32_t lds[];
-  const Lv lv = stage_level(p.level, lds);
+__global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
+  const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
   constexpr int WS = A + M + 2;
-  int type[M];
-  load_types<M>(lv, type);
   int32_t w[WS];
 #pragma unroll
   for (int r = 0; r < WS; r++) w[r] = p.state[(int64_t)r * p.n + i];
   Env<A, M> e;
   unpack<A, M>(e, w);
   const int C = p.cfg.num_comm;
-  const int F = 22 + lv.S + 2 * C;
+  const int F = 22 + L.S + 2 * C;
   const int c0 = p.comm[i], c1 = p.comm[p.n + i];
   const bool ego_blind = p.cfg.blind_mask & 1;
 #pragma unroll
   for (int v = 0; v < 2; v++)
-    env_obs<A, M>(lv, e, type, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1,
+    env_obs<A, M>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1,
                   p.obs + (int64_t)v * F * p.n + i, p.n);
-  p.timestep[i] = (double)e.t / (double)lv.T;          // overcooked_env.py:146
+  p.timestep[i] = (double)e.t / (double)p.R.T;  // overcooked_env.py:146
 }
 
 struct ResetArgs {
-  const uint32_t *level;
+  const int32_t *init;
   int32_t *state;
   const int32_t *mask;
   int64_t n;
+  int32_t words;
 };
 
-__global__ void __launch_bounds__(256) k_reset(ResetArgs p) {
-  const DevLevel *h = (const DevLevel *)p.level;
+__global__ void __launch_bounds__(256) k_reset(const ResetArgs p) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
   if (p.mask != nullptr && p.mask[i] == 0) return;
-  const int ws = h->A + h->M + 2;
-  for (int r = 0; r < ws; r++) p.state[(int64_t)r * p.n + i] = h->init_words[r];
+  for (int r = 0; r < p.words; r++) p.state[(int64_t)r * p.n + i] = p.init[r];
 }
 
 struct MultiArgs {
-  const uint32_t *level;
+  LevelHdr L;
+  RunCfg R;
+  const uint8_t *dist;
+  const double *quot;
   int32_t *state;
   int32_t *comm;
   const int32_t *actions;
@@ -699,25 +675,22 @@ struct MultiArgs {
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
 template <int M>
-__global__ void __launch_bounds__(256) k_multi_step(MultiArgs p) {
+__global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
   constexpr int A = 2;
-  extern __shared__ uint32_t lds[];
-  const Lv lv = stage_level(p.level, lds);
+  const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < p.n;
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
     constexpr int WS = A + M + 2;
-    int type[M];
-    load_types<M>(lv, type);
     int32_t w[WS];
 #pragma unroll
     for (int r = 0; r < WS; r++) w[r] = p.state[(int64_t)r * p.n + i];
-    Env<A, M> e;
-    unpack<A, M>(e, w);
     const int ego_mv = p.actions[i], ego_cm = p.actions[p.n + i];
     const int alt_mv = p.actions[2 * p.n + i], alt_cm = p.actions[3 * p.n + i];
+    Env<A, M> e;
+    unpack<A, M>(e, w);
     // comm one-hots (:227-246)
     const int c0 = p.cfg.communication_on ? ego_cm : -1;
     const int c1 = (p.cfg.communication_on && !p.cfg.ego_led) ? alt_cm : -1;
@@ -731,15 +704,15 @@ __global__ void __launch_bounds__(256) k_multi_step(MultiArgs p) {
     act[1] = p.cfg.ego_agent_idx == 0 ? am : em;
     const int err_before = e.err;
     double s0, s1;
-    env_step<A, M>(lv, e, type, act, reward, done, success, s0, s1);
+    env_step<A, M>(L, p.R, p.dist, p.quot, e, act, reward, done, success, s0, s1);
     comp = e.completed;
     err = e.err != err_before;
-    p.reward[i] = ((double)reward - s0) - s1;          // :282
+    p.reward[i] = ((double)reward - s0) - s1;  // :282
     p.done[i] = done;
     if (p.sparse != nullptr) p.sparse[i] = reward;
     if (done && p.auto_reset) {
 #pragma unroll
-      for (int r = 0; r < WS; r++) w[r] = lv.h->init_words[r];
+      for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
       unpack<A, M>(e, w);
     } else {
       pack<A, M>(e, w);
@@ -747,38 +720,44 @@ __global__ void __launch_bounds__(256) k_multi_step(MultiArgs p) {
 #pragma unroll
     for (int r = 0; r < WS; r++) p.state[(int64_t)r * p.n + i] = w[r];
     const int C = p.cfg.obs.num_comm;
-    const int F = 22 + lv.S + 2 * C;
+    const int F = 22 + L.S + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
 #pragma unroll
     for (int v = 0; v < 2; v++)
-      env_obs<A, M>(lv, e, type, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C,
-                    c0, c1, p.obs + (int64_t)v * F * p.n + i, p.n);
-    p.timestep[i] = (double)e.t / (double)lv.T;
+      env_obs<A, M>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1,
+                    p.obs + (int64_t)v * F * p.n + i, p.n);
+    p.timestep[i] = (double)e.t / (double)p.R.T;
   }
-  accumulate_metrics(p.metrics, valid, done, success, reward, comp, err);
+  accumulate_metrics(p.metrics, i, valid, done, success, reward, comp, err);
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 int block_size_for(int64_t n) {
-  // small batches: spread over more CUs (one wave per workgroup); large batches:
-  // amortise the per-workgroup level staging over four waves
+  // small batches: one wave per workgroup, so the work spreads over more CUs
   return n >= 256 * 256 ? 256 : 64;
 }
 
 template <typename Args, typename K>
-int launch(K kernel, const oc_level *lv, const Args &args, int64_t n, void *stream) {
+int launch(K kernel, const Args &args, int64_t n, void *stream) {
   if (n == 0) return OC_OK;
   const int bs = block_size_for(n);
   const int64_t grid = (n + bs - 1) / bs;
   if (grid > 0x7FFFFFFF) return fail(OC_E_BADARG, "n too large");
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(bs), lv->image_bytes, (hipStream_t)stream, args);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(bs), 0, (hipStream_t)stream, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "kernel launch");
   return OC_OK;
 }
 
+#ifdef OC_SPECIALIZED
+#define OC_DISPATCH_AM(KERNEL, A_, M_, ...)                                                  \
+  do {                                                                                       \
+    if (A_ == OC_SPEC_HDR.A && M_ == OC_SPEC_HDR.M) return launch(KERNEL<OC_SPEC_HDR.A, OC_SPEC_HDR.M>, __VA_ARGS__); \
+    return fail(OC_E_BADARG, "specialised library built for another (num_agents, num_items)"); \
+  } while (0)
+#else
 #define OC_DISPATCH_AM(KERNEL, A_, M_, ...)                                      \
   do {                                                                           \
     if (A_ == 2 && M_ == 3) return launch(KERNEL<2, 3>, __VA_ARGS__);            \
@@ -789,6 +768,110 @@ int launch(K kernel, const oc_level *lv, const Args &args, int64_t n, void *stre
     if (A_ == 4 && M_ == 4) return launch(KERNEL<4, 4>, __VA_ARGS__);            \
     return fail(OC_E_BADARG, "unsupported (num_agents, num_items): need A in 2..4, M in 3..4"); \
   } while (0)
+#endif
+
+int tset_of_sig(int sig) {
+  int ts = 0;
+  for (int t = 0; t < OC_NTYPES; t++)
+    if ((sig >> (4 * t)) & 15) ts |= 1 << t;
+  return ts;
+}
+
+// Level blob (include/oc_level.h) -> LevelHdr + RunCfg.  Host only, no device work.
+// Returns NULL on success, else a message.
+const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg &run) {
+  if (!b || n_words < OC_LV_HEADER_WORDS) return "null or short blob";
+  if (b[OC_LV_MAGIC] != OC_LV_MAGIC_VALUE || b[OC_LV_VERSION] != OC_LV_VERSION_VALUE ||
+      b[OC_LV_TOTAL] != n_words)
+    return "bad magic/version/length";
+  const int W = b[OC_LV_W], H = b[OC_LV_H], A = b[OC_LV_A], M = b[OC_LV_M], S = b[OC_LV_S];
+  const int nc = W * H;
+  if (W < 1 || H < 1 || W > 16 || H > 16 || nc > OC_MAX_CELLS || A < 2 || A > OC_MAX_AGENTS || M < 1 ||
+      M > OC_MAX_ITEMS || S < 1 || S > OC_MAX_SUBTASKS || b[OC_LV_NPAIR] > OC_MAX_PAIR ||
+      b[OC_LV_NDELIV] < 1 || b[OC_LV_NDELIV] > OC_MAX_DELIV || b[OC_LV_MAX_PATH] > 255 ||
+      b[OC_LV_T] < 0 || b[OC_LV_T] > 0xFFFF)
+    return "level dimensions out of range";
+  memset(&h, 0, sizeof(h));
+  h.W = W; h.H = H; h.A = A; h.M = M; h.S = S; h.max_path = b[OC_LV_MAX_PATH]; h.ncells = nc;
+  run.T = b[OC_LV_T];
+  run.allergic = (uint32_t)b[OC_LV_ALLERGIC];
+  const int32_t *cells = b + b[OC_LV_OFF_CELLS];
+  const int32_t *ag = b + b[OC_LV_OFF_AGENTS], *it = b + b[OC_LV_OFF_ITEMS];
+  const int32_t *st = b + b[OC_LV_OFF_SUBTASKS], *pr = b + b[OC_LV_OFF_PAIR], *dl = b + b[OC_LV_OFF_DELIV];
+  for (int c = 0; c < nc; c++) {
+    const uint64_t bit = 1ull << (c & 63);
+    if (cells[c] != OC_FLOOR) h.nonfloor[c >> 6] |= bit;
+    if (cells[c] & 1) h.cell_lo[c >> 6] |= bit;
+    if (cells[c] & 2) h.cell_hi[c >> 6] |= bit;
+  }
+  for (int f = 0; f < 3; f++) h.food_item[f] = 255;
+  for (int i = 0; i < M; i++) {
+    const int t = it[3 * i];
+    if (t < 0 || t >= OC_NTYPES) return "bad item type";
+    if (t != OC_PLATE) {
+      if (h.food_item[t] != 255) return "a food type occurs twice (unsupported by the HIP path)";
+      h.food_item[t] = (uint32_t)i;
+    }
+    h.item_types |= (uint32_t)t << (4 * i);
+  }
+  for (int s = 0; s < S; s++) {
+    const int kind = st[4 * s], sig = st[4 * s + 1], food = st[4 * s + 2];
+    for (int t = 0; t < OC_NTYPES; t++)
+      if (((sig >> (4 * t)) & 15) > 1) return "goal object repeats a content type";
+    const int ts = tset_of_sig(sig);
+    if (kind == OC_DELIVER) {
+      h.deliver_mask |= 1u << s;
+      if (h.ndel >= (uint32_t)MAX_DELS) return "too many Deliver subtasks";
+      h.del_tset[h.ndel] = (uint32_t)ts;
+      h.del_bit[h.ndel] = (uint32_t)s;
+      h.ndel++;
+    } else {
+      h.nondeliver_mask |= 1u << s;
+      if (kind == OC_CHOP) {
+        if (food < 0 || food > 2 || h.food_item[food] == 255) return "Chop of an absent food";
+        h.chop_mask[food] |= 1u << s;
+      }
+    }
+    uint32_t g = 0;
+    for (; g < h.ngoal; g++)
+      if (h.goal_tset[g] == (uint32_t)ts) break;
+    if (g == h.ngoal) {
+      if (h.ngoal >= (uint32_t)MAX_GOALS) return "too many distinct goal objects";
+      h.goal_tset[h.ngoal++] = (uint32_t)ts;
+    }
+    if (kind == OC_DELIVER) h.goal_dl[g] |= 1u << s; else h.goal_nd[g] |= 1u << s;
+  }
+  // pair term: Plate + recipe[0] ingredient names, every unordered pair in that order
+  // (overcooked_environment.py:319-363); one distance lookup per item pair
+  for (int p = 0; p < b[OC_LV_NPAIR]; p++)
+    for (int q = p + 1; q < b[OC_LV_NPAIR]; q++) {
+      int cnt = 0;
+      for (int i = 0; i < M; i++)
+        for (int j = 0; j < M; j++)
+          if (it[3 * i] == pr[p] && it[3 * j] == pr[q]) {
+            if (h.npairlk >= (uint32_t)MAX_PAIRLK) return "too many item pairs in the shaping pair term";
+            h.pairlk[h.npairlk++] = (uint32_t)(i | (j << 4));
+            cnt++;
+          }
+      if (cnt) h.pairlk[h.npairlk - 1] |= 1u << 8; else h.pair_static_max++;
+    }
+  h.ndeliv = (uint32_t)b[OC_LV_NDELIV];
+  for (uint32_t k = 0; k < h.ndeliv; k++) h.deliv_pos[k] = (uint32_t)(dl[2 * k] | (dl[2 * k + 1] << 4));
+  // initial state words: OvercookedEnvironment.reset() (overcooked_environment.py:180-206)
+  for (int a = 0; a < A; a++) h.init_words[a] = ag[2 * a] | (ag[2 * a + 1] << 4);
+  for (int i = 0; i < M; i++)
+    h.init_words[A + i] = it[3 * i + 1] | (it[3 * i + 2] << 4) | (i << 9) | (i << 16) | ((1 << it[3 * i]) << 24);
+  {
+    int n_chop = 0, n_groups = (int)h.pair_static_max;
+    for (int f = 0; f < 3; f++) n_chop += __builtin_popcount(h.chop_mask[f]);
+    for (uint32_t k = 0; k < h.npairlk; k++) n_groups += (h.pairlk[k] >> 8) & 1;
+    int kmax = h.max_path + 64;                                          // Deliver term: distance + manhattan
+    if (2 * n_chop * h.max_path > kmax) kmax = 2 * n_chop * h.max_path;  // Chop term numerator
+    if (n_groups * h.max_path > kmax) kmax = n_groups * h.max_path;      // pair term numerator
+    h.nquot = (uint32_t)(kmax + 2);
+  }
+  return nullptr;
+}
 
 }  // namespace
 
@@ -797,65 +880,105 @@ extern "C" {
 int oc_abi_version(void) { return OC_ABI_VERSION; }
 const char *oc_last_error(void) { return g_err; }
 
+int oc_is_specialized(void) {
+#ifdef OC_SPECIALIZED
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+int oc_level_spec_source(const int32_t *b, int32_t n_words, char *buf, int32_t buf_size) {
+  LevelHdr h;
+  RunCfg run;
+  const char *msg = build_header(b, n_words, h, run);
+  if (msg) {
+    snprintf(g_err, sizeof(g_err), "oc_level_spec_source: %s", msg);
+    return OC_E_BADARG;
+  }
+  if (!buf || buf_size < 64) return fail(OC_E_BADARG, "oc_level_spec_source: buffer too small");
+  // LevelHdr holds 32-bit words and three pairs of 64-bit planes; emit it field by field
+  // in declaration order as one aggregate initialiser.
+  int n = 0;
+#define EMIT(...) do { n += snprintf(buf + n, n < buf_size ? (size_t)(buf_size - n) : 0, __VA_ARGS__); } while (0)
+  EMIT("// generated by oc_level_spec_source -- do not edit\n");
+  EMIT("constexpr LevelHdr OC_SPEC_HDR = {\n  %d, %d, %d, %d, %d, %d, %d,\n  0x%xu,\n", h.W, h.H, h.ncells,
+       h.max_path, h.S, h.A, h.M, h.item_types);
+  const uint64_t *planes[3] = {h.nonfloor, h.cell_lo, h.cell_hi};
+  for (int k = 0; k < 3; k++)
+    EMIT("  {0x%llxull, 0x%llxull},\n", (unsigned long long)planes[k][0], (unsigned long long)planes[k][1]);
+  EMIT("  0x%xu, 0x%xu,\n", h.nondeliver_mask, h.deliver_mask);
+#define EMIT_ARR(arr, cnt) do { EMIT("  {"); for (int k_ = 0; k_ < (cnt); k_++) EMIT("%s0x%xu", k_ ? ", " : "", (unsigned)(arr)[k_]); EMIT("},\n"); } while (0)
+  EMIT_ARR(h.chop_mask, 3);
+  EMIT_ARR(h.food_item, 3);
+  EMIT("  %uu,\n", h.ngoal);
+  EMIT_ARR(h.goal_tset, MAX_GOALS);
+  EMIT_ARR(h.goal_nd, MAX_GOALS);
+  EMIT_ARR(h.goal_dl, MAX_GOALS);
+  EMIT("  %uu,\n", h.ndel);
+  EMIT_ARR(h.del_tset, MAX_DELS);
+  EMIT_ARR(h.del_bit, MAX_DELS);
+  EMIT("  %uu,\n", h.npairlk);
+  EMIT_ARR(h.pairlk, MAX_PAIRLK);
+  EMIT("  %uu,\n  %uu,\n", h.pair_static_max, h.ndeliv);
+  EMIT_ARR(h.deliv_pos, OC_MAX_DELIV);
+  EMIT("  {");
+  for (int k = 0; k < OC_MAX_AGENTS + OC_MAX_ITEMS + 2; k++) EMIT("%s%d", k ? ", " : "", h.init_words[k]);
+  EMIT("},\n  %uu\n};\n", h.nquot);
+#undef EMIT_ARR
+#undef EMIT
+  if (n >= buf_size) return fail(OC_E_BADARG, "oc_level_spec_source: buffer too small");
+  return n;
+}
+
 int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
-  if (!b || !out || n_words < OC_LV_HEADER_WORDS) return fail(OC_E_BADARG, "oc_level_create: null or short blob");
-  if (b[OC_LV_MAGIC] != OC_LV_MAGIC_VALUE || b[OC_LV_VERSION] != OC_LV_VERSION_VALUE ||
-      b[OC_LV_TOTAL] != n_words)
-    return fail(OC_E_BADARG, "oc_level_create: bad magic/version/length");
-  const int W = b[OC_LV_W], H = b[OC_LV_H], A = b[OC_LV_A], M = b[OC_LV_M], S = b[OC_LV_S];
-  const int nc = W * H;
-  if (W < 1 || H < 1 || W > 16 || H > 16 || nc > OC_MAX_CELLS || A < 2 || A > OC_MAX_AGENTS || M < 1 ||
-      M > OC_MAX_ITEMS || S < 1 || S > OC_MAX_SUBTASKS || b[OC_LV_NPAIR] > OC_MAX_PAIR ||
-      b[OC_LV_NDELIV] < 1 || b[OC_LV_NDELIV] > OC_MAX_DELIV || b[OC_LV_MAX_PATH] > 255 ||
-      b[OC_LV_T] < 0 || b[OC_LV_T] > 0xFFFF)
-    return fail(OC_E_BADARG, "oc_level_create: level dimensions out of range");
+  if (!out) return fail(OC_E_BADARG, "oc_level_create: null out pointer");
   oc_level *lv = new (std::nothrow) oc_level();
   if (!lv) return fail(OC_E_BADARG, "oc_level_create: out of memory");
-  DevLevel &h = lv->host;
-  memset(&h, 0, sizeof(h));
-  h.W = W; h.H = H; h.A = A; h.M = M; h.S = S; h.T = b[OC_LV_T];
-  h.max_path = b[OC_LV_MAX_PATH]; h.allergic = b[OC_LV_ALLERGIC];
-  h.npair = b[OC_LV_NPAIR]; h.ndeliv = b[OC_LV_NDELIV]; h.ncells = nc;
-  const int32_t *cells = b + b[OC_LV_OFF_CELLS], *dist = b + b[OC_LV_OFF_DIST];
-  const int32_t *ag = b + b[OC_LV_OFF_AGENTS], *it = b + b[OC_LV_OFF_ITEMS];
-  const int32_t *st = b + b[OC_LV_OFF_SUBTASKS], *pr = b + b[OC_LV_OFF_PAIR], *dl = b + b[OC_LV_OFF_DELIV];
-  for (int i = 0; i < nc; i++) h.cells[i] = (uint8_t)cells[i];
-  int food_seen[OC_NTYPES] = {0, 0, 0, 0};
-  for (int i = 0; i < M; i++) {
-    const int t = it[3 * i];
-    if (t < 0 || t >= OC_NTYPES) { delete lv; return fail(OC_E_BADARG, "oc_level_create: bad item type"); }
-    if (t != OC_PLATE && food_seen[t]++) {
-      delete lv;
-      return fail(OC_E_BADARG, "oc_level_create: a food type occurs twice (unsupported by the HIP path)");
-    }
-    h.item_type[i] = (uint8_t)t;
-  }
-  for (int s = 0; s < S; s++) {
-    h.sub_kind[s] = (uint8_t)st[4 * s];
-    h.sub_sig[s] = (uint16_t)st[4 * s + 1];
-    h.sub_food[s] = (int8_t)st[4 * s + 2];
-  }
-  for (int p = 0; p < h.npair; p++) h.pair_type[p] = (uint8_t)pr[p];
-  for (int k = 0; k < h.ndeliv; k++) { h.deliv_x[k] = (uint8_t)dl[2 * k]; h.deliv_y[k] = (uint8_t)dl[2 * k + 1]; }
-  // initial state words: OvercookedEnvironment.reset() (overcooked_environment.py:180-206)
-  for (int a = 0; a < A; a++) h.init_words[a] = ag[2 * a] | (ag[2 * a + 1] << 4);
-  for (int i = 0; i < M; i++) h.init_words[A + i] = it[3 * i + 1] | (it[3 * i + 2] << 4) | (i << 9) | (i << 16);
-  h.init_words[A + M] = 0;
-  h.init_words[A + M + 1] = 0;
-  const size_t bytes = (sizeof(DevLevel) + (size_t)nc * nc + 3) & ~(size_t)3;
-  h.image_words = (int32_t)(bytes / 4);
-  lv->image_bytes = bytes;
-  uint8_t *img = new (std::nothrow) uint8_t[bytes];
-  if (!img) { delete lv; return fail(OC_E_BADARG, "oc_level_create: out of memory"); }
-  memset(img, 0, bytes);
-  memcpy(img, &h, sizeof(DevLevel));
-  for (int i = 0; i < nc * nc; i++) img[sizeof(DevLevel) + i] = (uint8_t)dist[i];
-  hipError_t e = hipGetDevice(&lv->device);
-  if (e == hipSuccess) e = hipMalloc(&lv->dev, bytes);
-  if (e == hipSuccess) e = hipMemcpy(lv->dev, img, bytes, hipMemcpyHostToDevice);
-  delete[] img;
-  if (e != hipSuccess) {
+  lv->dev_dist = nullptr;
+  lv->dev_quot = nullptr;
+  lv->dev_init = nullptr;
+  LevelHdr &h = lv->hdr;
+  const char *msg = build_header(b, n_words, h, lv->run);
+  if (msg) {
     delete lv;
+    snprintf(g_err, sizeof(g_err), "oc_level_create: %s", msg);
+    return OC_E_BADARG;
+  }
+#ifdef OC_SPECIALIZED
+  {
+    const LevelHdr spec = OC_SPEC_HDR;
+    if (memcmp(&spec, &h, sizeof(LevelHdr)) != 0) {
+      delete lv;
+      return fail(OC_E_BADARG, "oc_level_create: this library is specialised for a different level");
+    }
+  }
+#endif
+  const int nc = h.ncells;
+  const int32_t *dist = b + b[OC_LV_OFF_DIST];
+  // quotient table: every int / MAX_PATH the shaping formula can form (correctly rounded
+  // fp64 division, as CPython's int / int)
+  double *quot = new (std::nothrow) double[h.nquot];
+  uint8_t *d8 = new (std::nothrow) uint8_t[(size_t)nc * nc];
+  if (!quot || !d8) {
+    delete[] quot;
+    delete[] d8;
+    delete lv;
+    return fail(OC_E_BADARG, "oc_level_create: out of memory");
+  }
+  for (uint32_t k = 0; k < h.nquot; k++) quot[k] = (double)(int)k / (double)h.max_path;
+  for (int i = 0; i < nc * nc; i++) d8[i] = (uint8_t)dist[i];
+  hipError_t e = hipGetDevice(&lv->device);
+  if (e == hipSuccess) e = hipMalloc((void **)&lv->dev_dist, (size_t)nc * nc);
+  if (e == hipSuccess) e = hipMalloc((void **)&lv->dev_quot, sizeof(double) * h.nquot);
+  if (e == hipSuccess) e = hipMalloc((void **)&lv->dev_init, sizeof(h.init_words));
+  if (e == hipSuccess) e = hipMemcpy(lv->dev_dist, d8, (size_t)nc * nc, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(lv->dev_quot, quot, sizeof(double) * h.nquot, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(lv->dev_init, h.init_words, sizeof(h.init_words), hipMemcpyHostToDevice);
+  delete[] quot;
+  delete[] d8;
+  if (e != hipSuccess) {
+    oc_level_destroy(lv);
     fail_hip(e, "oc_level_create");
     return OC_E_NODEVICE;
   }
@@ -865,20 +988,23 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
 
 int oc_level_destroy(oc_level_t *lv) {
   if (!lv) return OC_OK;
-  if (lv->dev) (void)hipFree(lv->dev);
+  if (lv->dev_dist) (void)hipFree(lv->dev_dist);
+  if (lv->dev_quot) (void)hipFree(lv->dev_quot);
+  if (lv->dev_init) (void)hipFree(lv->dev_init);
   delete lv;
   return OC_OK;
 }
 
-int32_t oc_state_words(const oc_level_t *lv) { return lv ? lv->host.A + lv->host.M + 2 : 0; }
+int64_t oc_metrics_slots(int64_t n) { return n <= 0 ? 0 : (n + 63) / 64; }
+int32_t oc_state_words(const oc_level_t *lv) { return lv ? lv->hdr.A + lv->hdr.M + 2 : 0; }
 int32_t oc_obs_rows(const oc_level_t *lv, int32_t num_comm) {
-  return lv ? 22 + lv->host.S + 2 * num_comm : 0;
+  return lv ? 22 + lv->hdr.S + 2 * num_comm : 0;
 }
 
 int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, int64_t n, void *stream) {
   if (!lv || !state || n < 0) return fail(OC_E_BADARG, "oc_reset: bad argument");
   if (n == 0) return OC_OK;
-  ResetArgs a{(const uint32_t *)lv->dev, state, mask, n};
+  ResetArgs a{lv->dev_init, state, mask, n, lv->hdr.A + lv->hdr.M + 2};
   const int bs = 256;
   hipLaunchKernelGGL(k_reset, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
@@ -889,16 +1015,16 @@ int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_
             double *shaping, int32_t auto_reset, int64_t *metrics, int64_t n, void *stream) {
   if (!lv || !state || !actions || !reward || !done || !shaping || n < 0)
     return fail(OC_E_BADARG, "oc_step: bad argument");
-  StepArgs a{(const uint32_t *)lv->dev, state, actions, reward, done, shaping, metrics, n, auto_reset};
-  OC_DISPATCH_AM(k_step, lv->host.A, lv->host.M, lv, a, n, stream);
+  StepArgs a{lv->hdr, lv->run, lv->dev_dist, lv->dev_quot, state, actions, reward, done, shaping, metrics, n, auto_reset};
+  OC_DISPATCH_AM(k_step, lv->hdr.A, lv->hdr.M, a, n, stream);
 }
 
 int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, const oc_obs_cfg *cfg,
            int32_t *obs, double *timestep, int64_t n, void *stream) {
   if (!lv || !state || !comm || !cfg || !obs || !timestep || n < 0 || cfg->num_comm < 0 || cfg->num_comm > 64)
     return fail(OC_E_BADARG, "oc_obs: bad argument");
-  ObsArgs a{(const uint32_t *)lv->dev, state, comm, obs, timestep, n, *cfg};
-  OC_DISPATCH_AM(k_obs, lv->host.A, lv->host.M, lv, a, n, stream);
+  ObsArgs a{lv->hdr, lv->run, state, comm, obs, timestep, n, *cfg};
+  OC_DISPATCH_AM(k_obs, lv->hdr.A, lv->hdr.M, a, n, stream);
 }
 
 int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
@@ -907,13 +1033,17 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   if (!lv || !state || !comm || !actions || !cfg || !obs || !timestep || !reward || !done || n < 0 ||
       cfg->obs.num_comm < 0 || cfg->obs.num_comm > 64)
     return fail(OC_E_BADARG, "oc_multi_step: bad argument");
-  if (lv->host.A != 2)
+  if (lv->hdr.A != 2)
     return fail(OC_E_BADARG, "oc_multi_step: the gym_comm wrapper drives exactly 2 agents");
-  MultiArgs a{(const uint32_t *)lv->dev, state, comm, actions, obs, timestep, reward, done, sparse, metrics,
-              n, auto_reset, *cfg};
-  if (lv->host.M == 3) return launch(k_multi_step<3>, lv, a, n, stream);
-  if (lv->host.M == 4) return launch(k_multi_step<4>, lv, a, n, stream);
+  MultiArgs a{lv->hdr, lv->run, lv->dev_dist, lv->dev_quot, state, comm, actions, obs, timestep, reward, done, sparse,
+              metrics, n, auto_reset, *cfg};
+#ifdef OC_SPECIALIZED
+  return launch(k_multi_step<OC_SPEC_HDR.M>, a, n, stream);
+#else
+  if (lv->hdr.M == 3) return launch(k_multi_step<3>, a, n, stream);
+  if (lv->hdr.M == 4) return launch(k_multi_step<4>, a, n, stream);
   return fail(OC_E_BADARG, "oc_multi_step: unsupported number of items");
+#endif
 }
 
 }  // extern "C"

@@ -1,0 +1,25 @@
+"""Levels whose specialised kernel libraries the GPU tests exercise; __graft_entry__.build()
+pre-compiles them (plus the BASELINE configs) so a fresh GPU box needs no JIT."""
+import os
+
+from conftest import GOLDEN, compile_for, load_golden
+
+# (level, num_agents, T) compiled with the canonical subtask order
+SEEDED_CASES = [
+    ("open-divider_tomato", 2, 100), ("full-divider_salad", 2, 120), ("partial-divider_tl", 3, 100),
+    ("open-divider_salad", 2, 150), ("open-divider_tl", 3, 150), ("partial-divider_tomato", 4, 60),
+    ("open-divider_tl", 2, 200), ("partial-divider_salad", 4, 90),
+]
+# golden fixtures replayed on the specialised path as well (recorded subtask order)
+SPEC_GOLDEN = ["base_open-divider_tomato_a2.npz", "base_full-divider_salad_a2.npz",
+               "base_partial-divider_tl_a3.npz", "base_full-divider_tl_a4.npz",
+               "wrap_tomato_r2.npz", "wrap_salad_open_c5.npz", "wrap_tl_full_blind_allergic.npz"]
+
+
+def all_spec_levels():
+    from gym_comm_amd import compiler
+    out = [compiler.compile_level(l, a, t) for l, a, t in SEEDED_CASES]
+    for f in SPEC_GOLDEN:
+        _, st = load_golden(os.path.join(GOLDEN, f))
+        out.append(compile_for(st))
+    return out

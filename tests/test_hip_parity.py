@@ -10,11 +10,19 @@ import torch
 
 from conftest import compile_for, golden_files, load_golden
 from hip_util import assert_snapshots_equal, bits, scripted_then_random
+from spec_levels import SEEDED_CASES, SPEC_GOLDEN
 
 pytestmark = pytest.mark.gpu
 
 BASE = golden_files("base_")
 WRAP = golden_files("wrap_")
+# every fixture on the generic library; a subset also on the per-level specialised one
+BASE_RUNS = [(p, False) for p in BASE] + [(p, True) for p in BASE if os.path.basename(p) in SPEC_GOLDEN]
+WRAP_RUNS = [(p, False) for p in WRAP] + [(p, True) for p in WRAP if os.path.basename(p) in SPEC_GOLDEN]
+
+
+def _rid(run):
+    return os.path.basename(run[0]) + ("-spec" if run[1] else "")
 
 
 def _env(lv, n, **kw):
@@ -22,15 +30,17 @@ def _env(lv, n, **kw):
     return BatchedOvercooked(lv, num_envs=n, **kw)
 
 
-@pytest.mark.parametrize("path", BASE, ids=[os.path.basename(p) for p in BASE])
-def test_base_step_matches_reference_golden(path):
+@pytest.mark.parametrize("run", BASE_RUNS, ids=[_rid(r) for r in BASE_RUNS])
+def test_base_step_matches_reference_golden(run):
     """Replay every recorded tape of OvercookedEnvironment.step/reset; 96 lanes (one and
     a half waves) get the same actions and must all reproduce the reference."""
     from gym_comm_amd.state import unpack_state
+    path, spec = run
     z, st = load_golden(path)
     lv = compile_for(st)
     n = 96
-    env = _env(lv, n, auto_reset=False)
+    env = _env(lv, n, auto_reset=False, specialize_level=spec)
+    assert env.kernel_flavour == ("spec" if spec else "generic")
     K = len(z["t"])
     acts = torch.from_numpy(np.repeat(z["actions"].astype(np.int32)[:, :, None], n, axis=2)).cuda()
     hist_state, hist_r, hist_d, hist_s = [], [], [], []
@@ -67,14 +77,15 @@ def _wrap_env(st, lv, n, **kw):
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "step+obs"])
-@pytest.mark.parametrize("path", WRAP, ids=[os.path.basename(p) for p in WRAP])
-def test_wrapper_matches_reference_golden(path, fused):
+@pytest.mark.parametrize("run", WRAP_RUNS, ids=[_rid(r) for r in WRAP_RUNS])
+def test_wrapper_matches_reference_golden(run, fused):
     """OvercookedMultiEnv.multi_step / multi_reset / get_observation2 tapes, through the
     fused oc_multi_step kernel and through oc_step + oc_obs."""
+    path, spec = run
     z, st = load_golden(path)
     lv = compile_for(st)
     n = 70
-    env = _wrap_env(st, lv, n, auto_reset=False)
+    env = _wrap_env(st, lv, n, auto_reset=False, specialize_level=spec)
     C = st["num_communication"]
     # observation right after multi_reset()
     obs, ts = env.observe()
@@ -116,15 +127,12 @@ def test_wrapper_matches_reference_golden(path, fused):
     assert env.F == 22 + lv.num_subtasks + 2 * C
 
 
-CASES = [
-    ("open-divider_tomato", 2, 100), ("full-divider_salad", 2, 120), ("partial-divider_tl", 3, 100),
-    ("open-divider_salad", 2, 150), ("open-divider_tl", 3, 150), ("partial-divider_tomato", 4, 60),
-    ("open-divider_tl", 2, 200), ("partial-divider_salad", 4, 90),
-]
+CASES = SEEDED_CASES
 
 
+@pytest.mark.parametrize("spec", [False, True], ids=["generic", "spec"])
 @pytest.mark.parametrize("level,A,T", CASES, ids=["%s-a%d" % (c[0], c[1]) for c in CASES])
-def test_step_matches_oracle_seeded(level, A, T, oracle_lib):
+def test_step_matches_oracle_seeded(level, A, T, spec, oracle_lib):
     """Seeded action streams, every env different, auto-reset on: full state compare with
     the oracle after every step (ragged batch: 1000 envs = 15 waves + a 40-lane tail)."""
     from gym_comm_amd import compiler
@@ -133,7 +141,7 @@ def test_step_matches_oracle_seeded(level, A, T, oracle_lib):
     rng = np.random.default_rng(1234 + A)
     acts = scripted_then_random(rng, level, steps, A, n)
     ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
-    env = _env(lv, n, auto_reset=True)
+    env = _env(lv, n, auto_reset=True, specialize_level=spec)
     acts_d = torch.from_numpy(acts).cuda()
     tot_r = tot_d = 0
     for k in range(steps):
@@ -157,10 +165,11 @@ def test_step_matches_oracle_seeded(level, A, T, oracle_lib):
     assert tot_d > 0 and tot_r > 0
 
 
+@pytest.mark.parametrize("spec", [False, True], ids=["generic", "spec"])
 @pytest.mark.parametrize("level,T,C,radius", [("open-divider_tomato", 100, 2, 2),
                                               ("full-divider_salad", 120, 5, 1),
-                                              ("open-divider_tl", 150, 3, 3)])
-def test_multi_step_matches_oracle_seeded(level, T, C, radius, oracle_lib):
+                                              ("open-divider_tl", 200, 3, 3)])
+def test_multi_step_matches_oracle_seeded(level, T, C, radius, spec, oracle_lib):
     from gym_comm_amd import compiler
     lv = compiler.compile_level(level, 2, T)
     n, steps = 777, 200
@@ -170,7 +179,7 @@ def test_multi_step_matches_oracle_seeded(level, T, C, radius, oracle_lib):
     acts = np.stack([mv[:, 0], cm[:, 0], mv[:, 1], cm[:, 1]], axis=1).astype(np.int32)
     ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
     comm = np.zeros((2, n), np.int32)
-    env = _env(lv, n, num_communication=C, fow_radius=radius, auto_reset=True)
+    env = _env(lv, n, num_communication=C, fow_radius=radius, auto_reset=True, specialize_level=spec)
     acts_d = torch.from_numpy(acts).cuda()
     for k in range(steps):
         o, t, r, d = env.multi_step(acts_d[k])

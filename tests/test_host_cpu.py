@@ -176,12 +176,16 @@ print("rank", rank, "ok")
 
 def test_metrics_allgather_two_ranks_gloo(tmp_path):
     """world_size 2 on gloo: the N>1 path (shard + end-of-rollout all-gather + max-time)."""
+    import socket
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-         "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+         "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
         env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
