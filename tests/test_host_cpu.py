@@ -170,7 +170,7 @@ assert g["total"]["episodes"] == sum(range(1, world + 1)), g
 assert len(g["per_rank"]) == world and g["per_rank"][rank][1] == rank + 1
 assert ocdist.rank_seed(5, rank) != ocdist.rank_seed(5, (rank + 1) %% world)
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(%r, "rank_%%d.ok" %% rank), "w").write("ok")
 """
 
 
@@ -178,7 +178,7 @@ def test_metrics_allgather_two_ranks_gloo(tmp_path):
     """world_size 2 on gloo: the N>1 path (shard + end-of-rollout all-gather + max-time)."""
     import socket
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER % ROOT)
+    script.write_text(_WORKER % (ROOT, str(tmp_path)))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = str(sk.getsockname()[1])
@@ -188,4 +188,4 @@ def test_metrics_allgather_two_ranks_gloo(tmp_path):
          "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
         env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert (tmp_path / "rank_0.ok").exists() and (tmp_path / "rank_1.ok").exists()
