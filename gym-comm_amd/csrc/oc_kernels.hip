@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -74,6 +75,26 @@ struct RunCfg {
   uint32_t allergic;  // bit a: agent a is ALLERGIC
 };
 
+#ifdef OC_STAMPS
+// Diagnostic build only (never shipped, never timed): s_memtime stamps of the phases of
+// k_multi_step, written by lane 0 of every wave to a debug buffer nothing else reads
+// (cdna_hip_programming.md section 7, "In-kernel stamps").
+#define OC_STAMP(k)                                                                  \
+  do {                                                                               \
+    unsigned long long t_;                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    oc_tt[(k)] = t_;                                                                 \
+  } while (0)
+#define OC_STAMP_PARAM , unsigned long long (&oc_tt)[16]
+#define OC_STAMP_PASS , oc_tt
+#else
+#define OC_STAMP(k) do { } while (0)
+#define OC_STAMP_PARAM
+#define OC_STAMP_PASS
+#endif
+
 #ifdef OC_SPECIALIZED
 #include OC_SPEC_FILE  // constexpr LevelHdr OC_SPEC_HDR = {...};
 #define OC_HDR(p) OC_SPEC_HDR
@@ -86,8 +107,9 @@ struct RunCfg {
 struct oc_level {
   LevelHdr hdr;
   RunCfg run;
-  uint8_t *dev_dist;   // [ncells*ncells] u8
-  double *dev_quot;    // [nquot] (double)k / (double)max_path
+  void *dev_tables;    // [nquot] fp64 quotients k / max_path, then [ncells*ncells] u8 distances
+  int32_t n16;         // table bytes / 16 (rounded up)
+  int32_t quot_bytes;
   int32_t *dev_init;   // init words (for k_reset)
   int device;
 };
@@ -162,6 +184,32 @@ __device__ __forceinline__ int bit128(const uint64_t (&w)[2], int c) {
 __device__ __forceinline__ int item_type(const LevelHdr &L, int i) { return (L.item_types >> (4 * i)) & 15; }
 __device__ __forceinline__ int manhattan(int p, int q) { return iabs(px(p) - px(q)) + iabs(py(p) - py(q)); }
 
+// An [R][n] tensor of 4-byte (or 8-byte) elements addressed through a buffer resource:
+// the per-lane part of the address is one 32-bit byte offset (voffset), the row offset is
+// a scalar (soffset), so a row access costs no vector address arithmetic at all.  The
+// descriptor's record count bounds the whole tensor; the tail lanes of the last wave are
+// still masked by the caller because rows are contiguous.
+struct Rows {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff;      // lane byte offset inside a row
+  int rowbytes;  // n * element size
+  __device__ __forceinline__ Rows(const void *base, int64_t n, int rows, int64_t i, int elem = 4) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(n * rows * elem), 0x00020000);
+    voff = (int)i * elem;
+    rowbytes = (int)n * elem;
+  }
+  __device__ __forceinline__ int ld(int row) const {
+    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, row * rowbytes, 0);
+  }
+  __device__ __forceinline__ void st(int row, int v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, voff, row * rowbytes, 0);
+  }
+  __device__ __forceinline__ void st_f64(int row, double v) const {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), rsrc, voff, row * rowbytes, 0);
+  }
+};
+
 // ---------------------------------------------------------------------------
 // one environment tick: OvercookedEnvironment.step
 // (gym_cooking/envs/overcooked_environment.py:211-241)
@@ -170,7 +218,7 @@ template <int A, int M>
 __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
                                          const double *__restrict__ quot, Env<A, M> &e,
                                          const int (&act_in)[A], int &reward, int &done, int &success,
-                                         double &s0, double &s1) {
+                                         double &s0, double &s1 OC_STAMP_PARAM) {
   const int W = L.W, H = L.H;
   e.t += 1;  // :213
 
@@ -278,6 +326,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     e.mctr += do_merge ? 1 : 0;
   }
 
+  OC_STAMP(2);
   // ---- done (:243-270) and reward (:399-432) ---------------------------------
   // present / at_delivery: bit s set iff an Object with type-set s and every food chopped
   // exists (anywhere / on the first Delivery tile).  A multi-item Object is all-chopped
@@ -387,6 +436,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
       for (int b = 0; b < B; b++) d_tile[b] = min(d_tile[b], (int)dist[arow[b] + dc] + manhattan(e.ap[b], dp));
     }
 
+  OC_STAMP(3);   // distance lookups issued
   // Chop term (:278-304)
   int nchop = 0;
   int mind[B];
@@ -436,6 +486,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
         kq_del[k][b] = d == 0 ? d_tile[b] : d;
       }
     }
+  OC_STAMP(4);   // distances consumed
   const int qmax = (int)L.nquot - 1;
   double q_chop[B], q_pair, q_del[MAX_DELS][B];
 #pragma unroll
@@ -446,6 +497,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
 #pragma unroll
     for (int b = 0; b < B; b++) q_del[k][b] = (k < (int)L.ndel) ? quot[min(kq_del[k][b], qmax)] : 0.0;
 
+  OC_STAMP(5);   // quotient loads issued
   double tot[B];
 #pragma unroll
   for (int b = 0; b < B; b++) {
@@ -465,6 +517,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     }
   s0 = tot[0];
   s1 = B > 1 ? tot[1] : 0.0;
+  OC_STAMP(6);   // shaping done
 }
 
 // get_observation2 (gym_comm/envs/overcooked_env.py:105-159) for one viewer;
@@ -472,7 +525,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
 template <int A, int M>
 __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, int viewer, int radius,
                                         bool viewer_blind, bool ego_blind, int C, int comm0, int comm1,
-                                        int32_t *__restrict__ out, int64_t n) {
+                                        const Rows &out, int row0) {
   const int vp = viewer == 0 ? e.ap[0] : e.ap[1];
   const int vh = viewer == 0 ? e.ah[0] : e.ah[1];
   const int vx = px(vp), vy = py(vp);
@@ -499,65 +552,120 @@ __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, i
     ddx[ch] = within ? 0 : ddx[ch];                 // :135 (sic: zeroed when visible)
     ddy[ch] = within ? 0 : ddy[ch];
   }
-  int row = 0;
+  int row = row0;
 #pragma unroll
-  for (int ch = 0; ch < 4; ch++) out[(row++) * n] = ddx[ch];
+  for (int ch = 0; ch < 4; ch++) out.st(row++, ddx[ch]);
 #pragma unroll
-  for (int ch = 0; ch < 4; ch++) out[(row++) * n] = ddy[ch];
+  for (int ch = 0; ch < 4; ch++) out.st(row++, ddy[ch]);
 #pragma unroll
-  for (int ch = 0; ch < 4; ch++) out[(row++) * n] = st[ch];
+  for (int ch = 0; ch < 4; ch++) out.st(row++, st[ch]);
 #pragma unroll
-  for (int ch = 0; ch < 4; ch++) out[(row++) * n] = hid[ch];
-  for (int s = 0; s < L.S; s++) out[(row++) * n] = (e.completed >> s) & 1;
-  out[(row++) * n] = viewer_blind ? 0 : px(e.ap[0]);  // :139-143
-  out[(row++) * n] = viewer_blind ? 0 : py(e.ap[0]);
-  out[(row++) * n] = viewer_blind ? 0 : px(e.ap[1]);
-  out[(row++) * n] = viewer_blind ? 0 : py(e.ap[1]);
-  out[(row++) * n] = ego_blind ? 0 : (vh >= 0 ? 1 : 0);  // :154, gated on the EGO's BLIND flag
-  out[(row++) * n] = 0;
-  for (int c = 0; c < C; c++) out[(row++) * n] = comm0 == c ? 1 : 0;
-  for (int c = 0; c < C; c++) out[(row++) * n] = comm1 == c ? 1 : 0;
+  for (int ch = 0; ch < 4; ch++) out.st(row++, hid[ch]);
+  for (int s = 0; s < L.S; s++) out.st(row++, (e.completed >> s) & 1);
+  out.st(row++, viewer_blind ? 0 : px(e.ap[0]));  // :139-143
+  out.st(row++, viewer_blind ? 0 : py(e.ap[0]));
+  out.st(row++, viewer_blind ? 0 : px(e.ap[1]));
+  out.st(row++, viewer_blind ? 0 : py(e.ap[1]));
+  out.st(row++, ego_blind ? 0 : (vh >= 0 ? 1 : 0));  // :154, gated on the EGO's BLIND flag
+  out.st(row++, 0);
+  for (int c = 0; c < C; c++) out.st(row++, comm0 == c ? 1 : 0);
+  for (int c = 0; c < C; c++) out.st(row++, comm1 == c ? 1 : 0);
 }
 
-// wave-level metric accumulation: ballot/popcount for the flags, a butterfly sum for
-// the integers, then lane 0 adds them into the wave's OWN 64-byte slot of the metrics
-// tensor (int64 [ceil(n/64)][8]).  No atomics: round-1 v1 used one device-wide counter
-// set and its 2 048 same-address atomics per launch (~11 ns each) were 60 % of the
-// n = 131 072 launch.  Launches that share a metrics tensor are ordered by the stream.
-__device__ __forceinline__ int wave_sum(int v) {
+// wave-level metric accumulation: ballot/popcount for the flags and, bit-sliced, for the
+// small integers; lane k (k < 6) then adds counter k into the wave's OWN 64-byte slot of
+// the metrics tensor (int64 [ceil(n/64)][8]) -- one 48-byte load issued at kernel start,
+// one store at the end, no atomics.  (Round-1 v1 used one device-wide counter set: its
+// 2 048 same-address atomics per launch, ~11 ns each, were 60 % of the n = 131 072
+// launch.)  Launches that share a metrics tensor are ordered by the stream.
+// Sum over the wave of a small non-negative per-lane integer (< 2^BITS): one ballot +
+// scalar popcount per bit -- no cross-lane shuffles, a handful of SALU ops.
+template <int BITS>
+__device__ __forceinline__ int wave_sum_small(int v) {
+  int s = 0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  for (int b = 0; b < BITS; b++) s += __popcll(__ballot((v >> b) & 1)) << b;
+  return s;
 }
 
-__device__ __forceinline__ void accumulate_metrics(int64_t *metrics, int64_t env_index, bool valid, int done,
-                                                   int success, int reward, int completed_bits, bool err) {
-  if (metrics == nullptr) return;
-  const unsigned long long vmask = __ballot(valid);
-  const unsigned long long dmask = __ballot(valid && done);
-  const unsigned long long smask = __ballot(valid && success);
-  const unsigned long long emask = __ballot(valid && err);
-  const int rsum = wave_sum(valid ? reward : 0);
-  const int csum = wave_sum((valid && done) ? __popc(completed_bits) : 0);
-  if ((threadIdx.x & 63) == 0 && vmask) {
-    int64_t *m = metrics + (env_index >> 6) * OC_MET_COUNT;
-    m[OC_MET_ENV_STEPS] += __popcll(vmask);
-    if (dmask) m[OC_MET_EPISODES] += __popcll(dmask);
-    if (smask) m[OC_MET_SUCCESSES] += __popcll(smask);
-    if (rsum) m[OC_MET_REWARD_SUM] += rsum;
-    if (csum) m[OC_MET_COMPLETED_SUM] += csum;
-    if (emask) m[OC_MET_ERRORS] += __popcll(emask);
+struct MetricsSlot {
+  int64_t *p;
+  int64_t old;
+  __device__ __forceinline__ MetricsSlot(int64_t *metrics, int64_t env_index) {
+    const int lane = threadIdx.x & 63;
+    p = (metrics != nullptr && lane < 6) ? metrics + (env_index >> 6) * OC_MET_COUNT + lane : nullptr;
+    old = p ? *p : 0;
   }
-}
+  __device__ __forceinline__ void add(bool has_metrics, bool valid, int done, int success, int reward,
+                                      int completed_bits, bool err) {
+    if (!has_metrics) return;  // uniform
+    const int n_valid = __popcll(__ballot(valid));
+    const int n_done = __popcll(__ballot(valid && done));
+    const int n_succ = __popcll(__ballot(valid && success));
+    const int n_err = __popcll(__ballot(valid && err));
+    const int rsum = wave_sum_small<6>(valid ? reward : 0);   // reward <= 16 + 3 * MAX_DELS < 64
+    const int csum = wave_sum_small<5>((valid && done) ? __popc(completed_bits) : 0);
+    const int lane = threadIdx.x & 63;
+    const int v = lane == OC_MET_ENV_STEPS ? n_valid
+                : lane == OC_MET_EPISODES ? n_done
+                : lane == OC_MET_SUCCESSES ? n_succ
+                : lane == OC_MET_REWARD_SUM ? rsum
+                : lane == OC_MET_COMPLETED_SUM ? csum
+                : n_err;
+    if (p) *p = old + v;
+  }
+};
 
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
+// The two lane-indexed tables (fp64 quotients, then the u8 distance table) sit in one
+// device buffer.  Two variants of every step kernel exist (template bool LDS):
+//   LDS = false  the tables are read straight from global memory (vector L1/L2).  Best
+//                for small batches, where a workgroup is one wave and a staging pass +
+//                barrier is pure added latency (n = 4096: 4.7 us vs 5.7 us per step);
+//   LDS = true   every workgroup copies them to LDS with 16-byte loads issued BEFORE the
+//                state loads, so both round trips overlap.  Best once several waves
+//                share a CU (n = 131072: 11.3 us vs 13.2 us).
+// The launcher picks by batch size.
+struct Tables {
+  const double *quot;
+  const uint8_t *dist;
+};
+
+template <bool LDS>
+__device__ __forceinline__ Tables stage_tables(const void *__restrict__ tables, int n16, int quot_bytes) {
+  Tables tb;
+  if constexpr (LDS) {
+    extern __shared__ uint4 oc_lds[];
+    const uint4 *src = (const uint4 *)tables;
+    uint4 t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = threadIdx.x + k * blockDim.x;
+      if (idx < n16) t[k] = src[idx];
+    }
+    for (int idx = threadIdx.x + 4 * blockDim.x; idx < n16; idx += blockDim.x) oc_lds[idx] = src[idx];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = threadIdx.x + k * blockDim.x;
+      if (idx < n16) oc_lds[idx] = t[k];
+    }
+    __syncthreads();
+    tb.quot = (const double *)oc_lds;
+    tb.dist = (const uint8_t *)oc_lds + quot_bytes;
+  } else {
+    tb.quot = (const double *)tables;
+    tb.dist = (const uint8_t *)tables + quot_bytes;
+  }
+  return tb;
+}
+
 struct StepArgs {
   LevelHdr L;
   RunCfg R;
-  const uint8_t *dist;
-  const double *quot;
+  const void *tables;
+  int32_t n16, quot_bytes;
   int32_t *state;
   const int32_t *actions;
   int32_t *reward;
@@ -568,32 +676,39 @@ struct StepArgs {
   int32_t auto_reset;
 };
 
-template <int A, int M>
+template <int A, int M, bool LDS>
 __global__ void __launch_bounds__(256) k_step(const StepArgs p) {
   const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < p.n;
+  const Tables tb = stage_tables<LDS>(p.tables, p.n16, p.quot_bytes);
+  MetricsSlot slot(p.metrics, i);
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
     constexpr int WS = A + M + 2;
+    const Rows st(p.state, p.n, WS, i), ac(p.actions, p.n, A, i);
     int32_t w[WS];
 #pragma unroll
-    for (int r = 0; r < WS; r++) w[r] = p.state[(int64_t)r * p.n + i];
+    for (int r = 0; r < WS; r++) w[r] = st.ld(r);
     int act[A];
 #pragma unroll
-    for (int a = 0; a < A; a++) act[a] = p.actions[(int64_t)a * p.n + i];
+    for (int a = 0; a < A; a++) act[a] = ac.ld(a);
     Env<A, M> e;
     unpack<A, M>(e, w);
     const int err_before = e.err;
     double s0, s1;
-    env_step<A, M>(L, p.R, p.dist, p.quot, e, act, reward, done, success, s0, s1);
+#ifdef OC_STAMPS
+    unsigned long long oc_tt[16];
+#endif
+    env_step<A, M>(L, p.R, tb.dist, tb.quot, e, act, reward, done, success, s0, s1 OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     p.reward[i] = reward;
     p.done[i] = done;
-    p.shaping[i] = s0;
-    p.shaping[p.n + i] = s1;
+    const Rows sh(p.shaping, p.n, 2, i, 8);
+    sh.st_f64(0, s0);
+    sh.st_f64(1, s1);
     if (done && p.auto_reset) {
 #pragma unroll
       for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
@@ -601,9 +716,9 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs p) {
       pack<A, M>(e, w);
     }
 #pragma unroll
-    for (int r = 0; r < WS; r++) p.state[(int64_t)r * p.n + i] = w[r];
+    for (int r = 0; r < WS; r++) st.st(r, w[r]);
   }
-  accumulate_metrics(p.metrics, i, valid, done, success, reward, comp, err);
+  slot.add(p.metrics != nullptr, valid, done, success, reward, comp, err);
 }
 
 struct ObsArgs {
@@ -623,19 +738,20 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
   constexpr int WS = A + M + 2;
+  const Rows st(p.state, p.n, WS, i);
   int32_t w[WS];
 #pragma unroll
-  for (int r = 0; r < WS; r++) w[r] = p.state[(int64_t)r * p.n + i];
+  for (int r = 0; r < WS; r++) w[r] = st.ld(r);
   Env<A, M> e;
   unpack<A, M>(e, w);
   const int C = p.cfg.num_comm;
   const int F = 22 + L.S + 2 * C;
   const int c0 = p.comm[i], c1 = p.comm[p.n + i];
   const bool ego_blind = p.cfg.blind_mask & 1;
+  const Rows ob(p.obs, p.n, 2 * F, i);
 #pragma unroll
   for (int v = 0; v < 2; v++)
-    env_obs<A, M>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1,
-                  p.obs + (int64_t)v * F * p.n + i, p.n);
+    env_obs<A, M>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
   p.timestep[i] = (double)e.t / (double)p.R.T;  // overcooked_env.py:146
 }
 
@@ -657,8 +773,8 @@ __global__ void __launch_bounds__(256) k_reset(const ResetArgs p) {
 struct MultiArgs {
   LevelHdr L;
   RunCfg R;
-  const uint8_t *dist;
-  const double *quot;
+  const void *tables;
+  int32_t n16, quot_bytes;
   int32_t *state;
   int32_t *comm;
   const int32_t *actions;
@@ -674,28 +790,36 @@ struct MultiArgs {
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
-template <int M>
+template <int M, bool LDS>
 __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
   constexpr int A = 2;
   const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < p.n;
+#ifdef OC_STAMPS
+  unsigned long long oc_tt[16];
+  for (int k = 0; k < 16; k++) oc_tt[k] = 0;
+#endif
+  OC_STAMP(0);
+  const Tables tb = stage_tables<LDS>(p.tables, p.n16, p.quot_bytes);
+  MetricsSlot slot(p.metrics, i);
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
     constexpr int WS = A + M + 2;
+    const Rows st(p.state, p.n, WS, i), ac(p.actions, p.n, 4, i), cm(p.comm, p.n, 2, i);
     int32_t w[WS];
 #pragma unroll
-    for (int r = 0; r < WS; r++) w[r] = p.state[(int64_t)r * p.n + i];
-    const int ego_mv = p.actions[i], ego_cm = p.actions[p.n + i];
-    const int alt_mv = p.actions[2 * p.n + i], alt_cm = p.actions[3 * p.n + i];
+    for (int r = 0; r < WS; r++) w[r] = st.ld(r);
+    const int ego_mv = ac.ld(0), ego_cm = ac.ld(1), alt_mv = ac.ld(2), alt_cm = ac.ld(3);
     Env<A, M> e;
     unpack<A, M>(e, w);
+    OC_STAMP(1);   // state + actions arrived
     // comm one-hots (:227-246)
     const int c0 = p.cfg.communication_on ? ego_cm : -1;
     const int c1 = (p.cfg.communication_on && !p.cfg.ego_led) ? alt_cm : -1;
-    p.comm[i] = c0;
-    p.comm[p.n + i] = c1;
+    cm.st(0, c0);
+    cm.st(1, c1);
     // NAV_ACTIONS lookup + CAN_MOVE gating + ego_agent_idx (:248-262)
     const int em = (p.cfg.can_move_mask & 1) ? (ego_mv & 3) : OC_ACT_NOOP;
     const int am = (p.cfg.can_move_mask & 2) ? (alt_mv & 3) : OC_ACT_NOOP;
@@ -704,12 +828,14 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
     act[1] = p.cfg.ego_agent_idx == 0 ? am : em;
     const int err_before = e.err;
     double s0, s1;
-    env_step<A, M>(L, p.R, p.dist, p.quot, e, act, reward, done, success, s0, s1);
+    env_step<A, M>(L, p.R, tb.dist, tb.quot, e, act, reward, done, success, s0, s1 OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     p.reward[i] = ((double)reward - s0) - s1;  // :282
     p.done[i] = done;
+#ifndef OC_STAMPS
     if (p.sparse != nullptr) p.sparse[i] = reward;
+#endif
     if (done && p.auto_reset) {
 #pragma unroll
       for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
@@ -718,17 +844,27 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
       pack<A, M>(e, w);
     }
 #pragma unroll
-    for (int r = 0; r < WS; r++) p.state[(int64_t)r * p.n + i] = w[r];
+    for (int r = 0; r < WS; r++) st.st(r, w[r]);
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
+    const Rows ob(p.obs, p.n, 2 * F, i);
 #pragma unroll
     for (int v = 0; v < 2; v++)
-      env_obs<A, M>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1,
-                    p.obs + (int64_t)v * F * p.n + i, p.n);
+      env_obs<A, M>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
+                    v * F);
     p.timestep[i] = (double)e.t / (double)p.R.T;
   }
-  accumulate_metrics(p.metrics, i, valid, done, success, reward, comp, err);
+  OC_STAMP(7);   // every store issued
+  slot.add(p.metrics != nullptr, valid, done, success, reward, comp, err);
+  OC_STAMP(8);
+#ifdef OC_STAMPS
+  // the sparse-reward pointer doubles as the debug buffer in this build: int64 [waves][16]
+  if ((threadIdx.x & 63) == 0 && p.sparse != nullptr) {
+    long long *dbg = (long long *)p.sparse + (i >> 6) * 16;
+    for (int k = 0; k < 16; k++) dbg[k] = (long long)oc_tt[k];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -736,38 +872,45 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
 // ---------------------------------------------------------------------------
 int block_size_for(int64_t n) {
   // small batches: one wave per workgroup, so the work spreads over more CUs
+  static const int forced = getenv("OC_BLOCK") ? atoi(getenv("OC_BLOCK")) : 0;
+  if (forced == 64 || forced == 128 || forced == 256) return forced;
   return n >= 256 * 256 ? 256 : 64;
 }
 
+// rows are addressed with 32-bit byte offsets through a buffer descriptor
+bool fits_buffer(int64_t n, int64_t rows, int elem) { return n * rows * elem < (int64_t)0x7FFFFFFF; }
+
 template <typename Args, typename K>
-int launch(K kernel, const Args &args, int64_t n, void *stream) {
+int launch(K kernel, const Args &args, int64_t n, void *stream, size_t lds_bytes = 0) {
   if (n == 0) return OC_OK;
   const int bs = block_size_for(n);
   const int64_t grid = (n + bs - 1) / bs;
   if (grid > 0x7FFFFFFF) return fail(OC_E_BADARG, "n too large");
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(bs), 0, (hipStream_t)stream, args);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(bs), lds_bytes, (hipStream_t)stream, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "kernel launch");
   return OC_OK;
 }
 
+bool tables_in_lds(int64_t n) {
+  static const int forced = getenv("OC_TABLES_LDS") ? atoi(getenv("OC_TABLES_LDS")) : -1;
+  if (forced == 0 || forced == 1) return forced == 1;
+  return n >= 256 * 256;   // several waves per CU: see stage_tables()
+}
+
 #ifdef OC_SPECIALIZED
-#define OC_DISPATCH_AM(KERNEL, A_, M_, ...)                                                  \
-  do {                                                                                       \
-    if (A_ == OC_SPEC_HDR.A && M_ == OC_SPEC_HDR.M) return launch(KERNEL<OC_SPEC_HDR.A, OC_SPEC_HDR.M>, __VA_ARGS__); \
-    return fail(OC_E_BADARG, "specialised library built for another (num_agents, num_items)"); \
-  } while (0)
+#define OC_FOR_AM(X)                                                                     \
+  if (A_ == OC_SPEC_HDR.A && M_ == OC_SPEC_HDR.M) { X(OC_SPEC_HDR.A, OC_SPEC_HDR.M); }  \
+  return fail(OC_E_BADARG, "specialised library built for another (num_agents, num_items)");
 #else
-#define OC_DISPATCH_AM(KERNEL, A_, M_, ...)                                      \
-  do {                                                                           \
-    if (A_ == 2 && M_ == 3) return launch(KERNEL<2, 3>, __VA_ARGS__);            \
-    if (A_ == 2 && M_ == 4) return launch(KERNEL<2, 4>, __VA_ARGS__);            \
-    if (A_ == 3 && M_ == 3) return launch(KERNEL<3, 3>, __VA_ARGS__);            \
-    if (A_ == 3 && M_ == 4) return launch(KERNEL<3, 4>, __VA_ARGS__);            \
-    if (A_ == 4 && M_ == 3) return launch(KERNEL<4, 3>, __VA_ARGS__);            \
-    if (A_ == 4 && M_ == 4) return launch(KERNEL<4, 4>, __VA_ARGS__);            \
-    return fail(OC_E_BADARG, "unsupported (num_agents, num_items): need A in 2..4, M in 3..4"); \
-  } while (0)
+#define OC_FOR_AM(X)                          \
+  if (A_ == 2 && M_ == 3) { X(2, 3); }        \
+  if (A_ == 2 && M_ == 4) { X(2, 4); }        \
+  if (A_ == 3 && M_ == 3) { X(3, 3); }        \
+  if (A_ == 3 && M_ == 4) { X(3, 4); }        \
+  if (A_ == 4 && M_ == 3) { X(4, 3); }        \
+  if (A_ == 4 && M_ == 4) { X(4, 4); }        \
+  return fail(OC_E_BADARG, "unsupported (num_agents, num_items): need A in 2..4, M in 3..4");
 #endif
 
 int tset_of_sig(int sig) {
@@ -935,8 +1078,7 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   if (!out) return fail(OC_E_BADARG, "oc_level_create: null out pointer");
   oc_level *lv = new (std::nothrow) oc_level();
   if (!lv) return fail(OC_E_BADARG, "oc_level_create: out of memory");
-  lv->dev_dist = nullptr;
-  lv->dev_quot = nullptr;
+  lv->dev_tables = nullptr;
   lv->dev_init = nullptr;
   LevelHdr &h = lv->hdr;
   const char *msg = build_header(b, n_words, h, lv->run);
@@ -956,27 +1098,26 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
 #endif
   const int nc = h.ncells;
   const int32_t *dist = b + b[OC_LV_OFF_DIST];
-  // quotient table: every int / MAX_PATH the shaping formula can form (correctly rounded
-  // fp64 division, as CPython's int / int)
-  double *quot = new (std::nothrow) double[h.nquot];
-  uint8_t *d8 = new (std::nothrow) uint8_t[(size_t)nc * nc];
-  if (!quot || !d8) {
-    delete[] quot;
-    delete[] d8;
+  // tables buffer: the quotients k / MAX_PATH for every numerator the shaping formula can
+  // form (correctly rounded fp64 division, as CPython's int / int), then the u8 distances
+  lv->quot_bytes = (int32_t)(sizeof(double) * h.nquot);
+  const size_t bytes = ((size_t)lv->quot_bytes + (size_t)nc * nc + 15) & ~(size_t)15;
+  lv->n16 = (int32_t)(bytes / 16);
+  uint8_t *img = new (std::nothrow) uint8_t[bytes];
+  if (!img) {
     delete lv;
     return fail(OC_E_BADARG, "oc_level_create: out of memory");
   }
+  memset(img, 0, bytes);
+  double *quot = (double *)img;
   for (uint32_t k = 0; k < h.nquot; k++) quot[k] = (double)(int)k / (double)h.max_path;
-  for (int i = 0; i < nc * nc; i++) d8[i] = (uint8_t)dist[i];
+  for (int i = 0; i < nc * nc; i++) img[lv->quot_bytes + i] = (uint8_t)dist[i];
   hipError_t e = hipGetDevice(&lv->device);
-  if (e == hipSuccess) e = hipMalloc((void **)&lv->dev_dist, (size_t)nc * nc);
-  if (e == hipSuccess) e = hipMalloc((void **)&lv->dev_quot, sizeof(double) * h.nquot);
+  if (e == hipSuccess) e = hipMalloc(&lv->dev_tables, bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&lv->dev_init, sizeof(h.init_words));
-  if (e == hipSuccess) e = hipMemcpy(lv->dev_dist, d8, (size_t)nc * nc, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(lv->dev_quot, quot, sizeof(double) * h.nquot, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(lv->dev_tables, img, bytes, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(lv->dev_init, h.init_words, sizeof(h.init_words), hipMemcpyHostToDevice);
-  delete[] quot;
-  delete[] d8;
+  delete[] img;
   if (e != hipSuccess) {
     oc_level_destroy(lv);
     fail_hip(e, "oc_level_create");
@@ -988,8 +1129,7 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
 
 int oc_level_destroy(oc_level_t *lv) {
   if (!lv) return OC_OK;
-  if (lv->dev_dist) (void)hipFree(lv->dev_dist);
-  if (lv->dev_quot) (void)hipFree(lv->dev_quot);
+  if (lv->dev_tables) (void)hipFree(lv->dev_tables);
   if (lv->dev_init) (void)hipFree(lv->dev_init);
   delete lv;
   return OC_OK;
@@ -1002,8 +1142,8 @@ int32_t oc_obs_rows(const oc_level_t *lv, int32_t num_comm) {
 }
 
 int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, int64_t n, void *stream) {
+  if (lv && n == 0) return OC_OK;
   if (!lv || !state || n < 0) return fail(OC_E_BADARG, "oc_reset: bad argument");
-  if (n == 0) return OC_OK;
   ResetArgs a{lv->dev_init, state, mask, n, lv->hdr.A + lv->hdr.M + 2};
   const int bs = 256;
   hipLaunchKernelGGL(k_reset, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, (hipStream_t)stream, a);
@@ -1013,35 +1153,63 @@ int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, int64_t 
 
 int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_t *reward, int32_t *done,
             double *shaping, int32_t auto_reset, int64_t *metrics, int64_t n, void *stream) {
+  if (lv && n == 0) return OC_OK;
   if (!lv || !state || !actions || !reward || !done || !shaping || n < 0)
     return fail(OC_E_BADARG, "oc_step: bad argument");
-  StepArgs a{lv->hdr, lv->run, lv->dev_dist, lv->dev_quot, state, actions, reward, done, shaping, metrics, n, auto_reset};
-  OC_DISPATCH_AM(k_step, lv->hdr.A, lv->hdr.M, a, n, stream);
+  if (!fits_buffer(n, lv->hdr.A + lv->hdr.M + 2, 4) || !fits_buffer(n, 2, 8))
+    return fail(OC_E_BADARG, "oc_step: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
+  StepArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, actions, reward, done, shaping,
+             metrics, n, auto_reset};
+  const int A_ = lv->hdr.A, M_ = lv->hdr.M;
+  const size_t lds = (size_t)lv->n16 * 16;
+  if (tables_in_lds(n)) {
+#define OC_X(AA, MM) return launch(k_step<AA, MM, true>, a, n, stream, lds)
+    OC_FOR_AM(OC_X)
+#undef OC_X
+  } else {
+#define OC_X(AA, MM) return launch(k_step<AA, MM, false>, a, n, stream, 0)
+    OC_FOR_AM(OC_X)
+#undef OC_X
+  }
 }
 
 int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, const oc_obs_cfg *cfg,
            int32_t *obs, double *timestep, int64_t n, void *stream) {
+  if (lv && cfg && n == 0) return OC_OK;
   if (!lv || !state || !comm || !cfg || !obs || !timestep || n < 0 || cfg->num_comm < 0 || cfg->num_comm > 64)
     return fail(OC_E_BADARG, "oc_obs: bad argument");
+  if (!fits_buffer(n, 2 * (22 + lv->hdr.S + 2 * cfg->num_comm), 4))
+    return fail(OC_E_BADARG, "oc_obs: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
   ObsArgs a{lv->hdr, lv->run, state, comm, obs, timestep, n, *cfg};
-  OC_DISPATCH_AM(k_obs, lv->hdr.A, lv->hdr.M, a, n, stream);
+  const int A_ = lv->hdr.A, M_ = lv->hdr.M;
+#define OC_X(AA, MM) return launch(k_obs<AA, MM>, a, n, stream, 0)
+  OC_FOR_AM(OC_X)
+#undef OC_X
 }
 
 int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
                   const oc_wrap_cfg *cfg, int32_t *obs, double *timestep, double *reward, int32_t *done,
                   int32_t *sparse, int32_t auto_reset, int64_t *metrics, int64_t n, void *stream) {
+  if (lv && cfg && n == 0) return OC_OK;
   if (!lv || !state || !comm || !actions || !cfg || !obs || !timestep || !reward || !done || n < 0 ||
       cfg->obs.num_comm < 0 || cfg->obs.num_comm > 64)
     return fail(OC_E_BADARG, "oc_multi_step: bad argument");
   if (lv->hdr.A != 2)
     return fail(OC_E_BADARG, "oc_multi_step: the gym_comm wrapper drives exactly 2 agents");
-  MultiArgs a{lv->hdr, lv->run, lv->dev_dist, lv->dev_quot, state, comm, actions, obs, timestep, reward, done, sparse,
-              metrics, n, auto_reset, *cfg};
+  if (!fits_buffer(n, 2 * (22 + lv->hdr.S + 2 * cfg->obs.num_comm), 4))
+    return fail(OC_E_BADARG, "oc_multi_step: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
+  MultiArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, comm, actions, obs, timestep,
+              reward, done, sparse, metrics, n, auto_reset, *cfg};
+  const size_t lds = (size_t)lv->n16 * 16;
+  const bool in_lds = tables_in_lds(n);
 #ifdef OC_SPECIALIZED
-  return launch(k_multi_step<OC_SPEC_HDR.M>, a, n, stream);
+  if (in_lds) return launch(k_multi_step<OC_SPEC_HDR.M, true>, a, n, stream, lds);
+  return launch(k_multi_step<OC_SPEC_HDR.M, false>, a, n, stream, 0);
 #else
-  if (lv->hdr.M == 3) return launch(k_multi_step<3>, a, n, stream);
-  if (lv->hdr.M == 4) return launch(k_multi_step<4>, a, n, stream);
+  if (lv->hdr.M == 3) return in_lds ? launch(k_multi_step<3, true>, a, n, stream, lds)
+                                    : launch(k_multi_step<3, false>, a, n, stream, 0);
+  if (lv->hdr.M == 4) return in_lds ? launch(k_multi_step<4, true>, a, n, stream, lds)
+                                    : launch(k_multi_step<4, false>, a, n, stream, 0);
   return fail(OC_E_BADARG, "oc_multi_step: unsupported number of items");
 #endif
 }

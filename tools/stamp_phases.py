@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Diagnostic: where one wave of k_multi_step spends its cycles (s_memtime stamps).
+Builds a -DOC_STAMPS specialised library (never shipped, never timed), runs a few hundred
+steps and prints the median cycle count of every phase.  GPU box only."""
+import os
+import sys
+
+os.environ["OC_HIP_EXTRA_FLAGS"] = (os.environ.get("OC_HIP_EXTRA_FLAGS", "") + " -DOC_STAMPS").strip()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from gym_comm_amd.batched import BatchedOvercooked
+
+NAMES = ["start->state+actions in regs", "collisions+interact", "done/reward + issue distance loads",
+         "distances arrive + integer shaping", "issue quotient loads", "quotients arrive + fp64 sums",
+         "auto-reset, state store, obs x2, issue stores", "metrics"]
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    env = BatchedOvercooked("open-divider_tomato", num_agents=2, num_envs=n, max_num_timesteps=500,
+                            num_communication=2, auto_reset=True, specialize_level=True)
+    waves = (n + 63) // 64
+    dbg = torch.zeros((waves, 16), dtype=torch.int64, device="cuda")
+    env.reward = dbg.view(torch.int32)          # the stamps build writes its stamps through `sparse`
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    hi = torch.tensor([4, 2, 4, 2], device="cuda").view(4, 1)
+    rows = []
+    for k in range(300):
+        a = (torch.rand((4, n), generator=gen, device="cuda") * hi).to(torch.int32)
+        env.multi_step(a)
+        if k >= 100:
+            rows.append(dbg.cpu().numpy().copy())
+    t = np.stack(rows).astype(np.int64)          # [steps][waves][16]
+    d = np.diff(t[:, :, :9], axis=2)
+    med = np.median(d.reshape(-1, 8), axis=0)
+    tot = np.median(t[:, :, 8] - t[:, :, 0])
+    print("n = %d, %d waves; median shader cycles per phase (one wave):" % (n, waves))
+    for name, v in zip(NAMES, med):
+        print("  %-52s %8.0f  (%4.1f %%)" % (name, v, 100 * v / tot))
+    print("  %-52s %8.0f" % ("total (first stamp -> last stamp)", tot))
+    span = np.median(t[:, :, 8].max(axis=1) - t[:, :, 0].min(axis=1))
+    print("  first wave start -> last wave end: %.0f cycles" % span)
+
+
+if __name__ == "__main__":
+    main()
