@@ -64,11 +64,11 @@ def _declare(L):
     L.oc_state_words.restype = ctypes.c_int32
     L.oc_obs_rows.argtypes = [vp, ctypes.c_int32]
     L.oc_obs_rows.restype = ctypes.c_int32
-    L.oc_reset.argtypes = [vp, vp, vp, ctypes.c_int64, vp]
-    L.oc_step.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, ctypes.c_int64, vp]
+    L.oc_reset.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, vp]
+    L.oc_step.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, ctypes.c_int64, vp]
     L.oc_obs.argtypes = [vp, vp, vp, ctypes.POINTER(ObsCfg), vp, vp, ctypes.c_int64, vp]
     L.oc_multi_step.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
-                                ctypes.c_int32, vp, ctypes.c_int64, vp]
+                                ctypes.c_int32, vp, vp, vp, ctypes.c_int64, vp]
     for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_reset", "oc_step",
               "oc_obs", "oc_multi_step"):
         getattr(L, f).restype = ctypes.c_int

@@ -38,7 +38,8 @@ class BatchedOvercooked:
                  ego_config=None, partner_config=None, num_communication=2,
                  communication_on=True, ego_led=False, fow_radius=2, ego_agent_idx=0,
                  device="cuda", subtask_order=None, placements=None, level_dir=None,
-                 max_num_subtasks=14, auto_reset=True, track_metrics=True, specialize_level="auto"):
+                 max_num_subtasks=14, auto_reset=True, track_metrics=True, specialize_level="auto",
+                 seed=0, placement_mode="rng"):
         cfg = {"ALLERGIC": False, "BLIND": False, "CAN_MOVE": True}   # missing CAN_MOVE = True
         self.ego_config = dict(cfg, **(ego_config or {}))
         self.partner_config = dict(cfg, **(partner_config or {}))
@@ -91,6 +92,20 @@ class BatchedOvercooked:
                                       (1 if self.ego_config["CAN_MOVE"] else 0) |
                                       (2 if self.partner_config["CAN_MOVE"] else 0))
         self._layout = obs_layout(self.S, self.C)
+        # random-* levels: item start cells differ per env and per episode
+        self.placement = None
+        self.rng = None
+        if lv.random_placement:
+            if placement_mode == "rng":
+                g = torch.Generator(device="cpu").manual_seed(int(seed))
+                self.rng = torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64
+                                         ).to(torch.int32).to(self.device)
+            elif placement_mode == "host":
+                nominal = torch.tensor(lv.pack_placement([(x, y) for _, x, y in lv.items]),
+                                       dtype=torch.int32)
+                self.placement = nominal.view(-1, 1).repeat(1, n).contiguous().to(self.device)
+            else:
+                raise ValueError("placement_mode must be 'rng' or 'host'")
         self.reset()
 
     def __del__(self):
@@ -121,8 +136,17 @@ class BatchedOvercooked:
         """Reset all envs, or those with mask[n] != 0 (int32 [n])."""
         if mask is not None:
             self._check_tensor(mask, (self.n,), torch.int32, "mask")
-        _lib.check(self._L.oc_reset(self._h, self._p(self.state), self._p(mask), self.n,
+        _lib.check(self._L.oc_reset(self._h, self._p(self.state), self._p(mask),
+                                    self._p(self.placement), self._p(self.rng), self.n,
                                     self._stream()), "oc_reset", self._L)
+
+    def set_placement(self, placement: torch.Tensor):
+        """placement_mode='host': the start cells (int32 [M][n], x | y<<4, world order) every
+        env uses at its next reset / auto-reset."""
+        if self.placement is None:
+            raise ValueError("this env was not created with placement_mode='host' on a random-* level")
+        self._check_tensor(placement, (self.M, self.n), torch.int32, "placement")
+        self.placement.copy_(placement)
 
     def step(self, actions: torch.Tensor, auto_reset: Optional[bool] = None):
         """Base-env step.  actions: int32 [A][n] action codes 0..4 (4 = stay).
@@ -132,7 +156,8 @@ class BatchedOvercooked:
         ar = self.auto_reset if auto_reset is None else auto_reset
         _lib.check(self._L.oc_step(self._h, self._p(self.state), self._p(actions),
                                    self._p(self.reward), self._p(self.done), self._p(self.shaping),
-                                   int(ar), self._p(self.metrics), self.n, self._stream()), "oc_step", self._L)
+                                   int(ar), self._p(self.metrics), self._p(self.placement),
+                                   self._p(self.rng), self.n, self._stream()), "oc_step", self._L)
         return self.reward, self.done, self.shaping
 
     def observe(self):
@@ -152,7 +177,8 @@ class BatchedOvercooked:
             self._h, self._p(self.state), self._p(self.comm), self._p(actions),
             ctypes.byref(self._wrap_cfg), self._p(self.obs), self._p(self.timestep),
             self._p(self.shaped_reward), self._p(self.done), self._p(self.reward), int(ar),
-            self._p(self.metrics), self.n, self._stream()), "oc_multi_step", self._L)
+            self._p(self.metrics), self._p(self.placement), self._p(self.rng), self.n,
+            self._stream()), "oc_multi_step", self._L)
         return self.obs, self.timestep, self.shaped_reward, self.done
 
     def obs_dict(self, viewer: int):

@@ -24,8 +24,8 @@ import numpy as np
 from . import levels as L
 
 MAGIC = 0x4F434C56          # 'OCLV'
-VERSION = 1
-HEADER_WORDS = 24
+VERSION = 2
+HEADER_WORDS = 32
 MAX_AGENTS = 4
 MAX_ITEMS = 8
 MAX_SUBTASKS = 16
@@ -358,6 +358,8 @@ class CompiledLevel:
     pair_types: List[int]             # Plate + recipe[0] ingredients sorted by name
     delivery: List[Tuple[int, int]]
     allergic_mask: int
+    counters: List[Tuple[int, int]] = field(default_factory=list)   # Counter tiles, world order
+    scatter_items: List[int] = field(default_factory=list)          # item ids placed at random per reset
     blob: np.ndarray = field(default=None, repr=False)
 
     @property
@@ -371,6 +373,15 @@ class CompiledLevel:
     @property
     def num_subtasks(self):
         return len(self.subtasks)
+
+    @property
+    def random_placement(self):
+        """True for random-* levels: item start cells differ per env and per episode."""
+        return len(self.scatter_items) > 0
+
+    def pack_placement(self, cells):
+        """[(x, y)] per item (world order) -> packed x | y<<4 words."""
+        return [int(x) | (int(y) << 4) for x, y in cells]
 
     @property
     def hip_supported(self):
@@ -388,8 +399,9 @@ def world_order_items(spec: L.LevelSpec, placements=None) -> List[Tuple[int, int
     seq = list(spec.map_items)
     if spec.scatter:
         if placements is None:
-            raise ValueError("level %r scatters %r on random Counters; pass placements="
-                             % (spec.name, spec.scatter))
+            # nominal start cells (the first Counters); the real ones are per env and per
+            # episode and are supplied / sampled at reset time
+            placements = spec.counters[:len(spec.scatter)]
         if len(placements) != len(spec.scatter):
             raise ValueError("need %d placements" % len(spec.scatter))
         for ch, (x, y) in zip(spec.scatter, placements):
@@ -401,7 +413,20 @@ def world_order_items(spec: L.LevelSpec, placements=None) -> List[Tuple[int, int
     first = {}
     for t, _, _ in seq:
         first.setdefault(t, len(first))
-    return sorted(seq, key=lambda it: first[it[0]])     # stable: keeps scan order per type
+    order = sorted(range(len(seq)), key=lambda k: first[seq[k][0]])   # stable: scan order per type
+    return [seq[k] for k in order]
+
+
+def scatter_item_ids(spec: L.LevelSpec) -> List[int]:
+    """World-order item id of every scattered letter, in the level file's letter order."""
+    seq = [t for t, _, _ in spec.map_items] + [L.TYPE_OF_CHAR[ch] for ch in spec.scatter]
+    first = {}
+    for t in seq:
+        first.setdefault(t, len(first))
+    order = sorted(range(len(seq)), key=lambda k: first[seq[k]])
+    pos = {k: i for i, k in enumerate(order)}
+    n_map = len(spec.map_items)
+    return [pos[n_map + j] for j in range(len(spec.scatter))]
 
 
 def compile_level(level, num_agents: int, max_num_timesteps: int = 100,
@@ -440,7 +465,9 @@ def compile_level(level, num_agents: int, max_num_timesteps: int = 100,
         max_num_timesteps=int(max_num_timesteps), cells=cells, dist=dist,
         agents=list(spec.agent_starts[:num_agents]), items=items, subtasks=subtasks,
         recipes=list(spec.recipes), pair_types=pair_types, delivery=delivery,
-        allergic_mask=allergic)
+        allergic_mask=allergic, counters=list(spec.counters), scatter_items=scatter_item_ids(spec))
+    if len(lv.counters) > 64:
+        raise ValueError("too many Counter tiles")
     lv.blob = build_blob(lv)
     return lv
 
@@ -451,15 +478,16 @@ def build_blob(lv: CompiledLevel) -> np.ndarray:
     off = HEADER_WORDS
     for key, size in (("cells", n), ("dist", n * n), ("agents", 2 * lv.num_agents),
                       ("items", 3 * lv.num_items), ("subtasks", 4 * lv.num_subtasks),
-                      ("pair", len(lv.pair_types)), ("delivery", 2 * len(lv.delivery))):
+                      ("pair", len(lv.pair_types)), ("delivery", 2 * len(lv.delivery)),
+                      ("counters", 2 * len(lv.counters)), ("scatter", len(lv.scatter_items))):
         sec[key] = off
         off += size
     b = np.zeros(off, dtype=np.int32)
     b[0:16] = [MAGIC, VERSION, lv.width, lv.height, lv.num_agents, lv.num_items,
                lv.num_subtasks, lv.max_num_timesteps, lv.max_path, lv.allergic_mask,
-               len(lv.pair_types), len(lv.delivery), 0, 0, 0, 0]
-    b[16:24] = [sec["cells"], sec["dist"], sec["agents"], sec["items"], sec["subtasks"],
-                sec["pair"], sec["delivery"], off]
+               len(lv.pair_types), len(lv.delivery), len(lv.counters), len(lv.scatter_items), 0, 0]
+    b[16:26] = [sec["cells"], sec["dist"], sec["agents"], sec["items"], sec["subtasks"],
+                sec["pair"], sec["delivery"], off, sec["counters"], sec["scatter"]]
     b[sec["cells"]:sec["cells"] + n] = lv.cells.reshape(-1)
     b[sec["dist"]:sec["dist"] + n * n] = lv.dist.reshape(-1)
     b[sec["agents"]:sec["agents"] + 2 * lv.num_agents] = np.array(lv.agents).reshape(-1)
@@ -471,4 +499,8 @@ def build_blob(lv: CompiledLevel) -> np.ndarray:
     b[sec["pair"]:sec["pair"] + len(lv.pair_types)] = lv.pair_types
     if lv.delivery:
         b[sec["delivery"]:sec["delivery"] + 2 * len(lv.delivery)] = np.array(lv.delivery).reshape(-1)
+    if lv.counters:
+        b[sec["counters"]:sec["counters"] + 2 * len(lv.counters)] = np.array(lv.counters).reshape(-1)
+    if lv.scatter_items:
+        b[sec["scatter"]:sec["scatter"] + len(lv.scatter_items)] = lv.scatter_items
     return b

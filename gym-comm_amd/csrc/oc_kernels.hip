@@ -67,6 +67,9 @@ struct LevelHdr {
   uint32_t deliv_pos[OC_MAX_DELIV];  // x | y<<4, world order
   int32_t init_words[OC_MAX_AGENTS + OC_MAX_ITEMS + 2];
   uint32_t nquot;  // entries in the quotient table
+  // random-* levels: items placed on random Counter tiles at every reset
+  uint32_t nscatter, ncounters;
+  uint32_t scatter_item[4];  // world-order item id of each scattered letter, file order
 };
 
 // per-run settings that do not select a specialisation
@@ -110,7 +113,6 @@ struct oc_level {
   void *dev_tables;    // [nquot] fp64 quotients k / max_path, then [ncells*ncells] u8 distances
   int32_t n16;         // table bytes / 16 (rounded up)
   int32_t quot_bytes;
-  int32_t *dev_init;   // init words (for k_reset)
   int device;
 };
 
@@ -631,6 +633,7 @@ struct MetricsSlot {
 struct Tables {
   const double *quot;
   const uint8_t *dist;
+  const uint8_t *counters;  // Counter tiles (x | y<<4), world order, 64 bytes
 };
 
 template <bool LDS>
@@ -654,11 +657,61 @@ __device__ __forceinline__ Tables stage_tables(const void *__restrict__ tables, 
     __syncthreads();
     tb.quot = (const double *)oc_lds;
     tb.dist = (const uint8_t *)oc_lds + quot_bytes;
+    tb.counters = (const uint8_t *)oc_lds + (n16 * 16 - OC_MAX_COUNTERS);
   } else {
     tb.quot = (const double *)tables;
     tb.dist = (const uint8_t *)tables + quot_bytes;
+    tb.counters = (const uint8_t *)tables + (n16 * 16 - OC_MAX_COUNTERS);
   }
   return tb;
+}
+
+// Start cells of the items for a fresh episode of a random-* level
+// (overcooked_environment.py:157-173: for every scattered letter, random.choice over ALL
+// Counter tiles until one not yet taken by this phase comes up).  Either read from the
+// caller's `placement` tensor ([M][n], x | y<<4; parity mode: the reference's own draws)
+// or drawn here from the env's own PCG32 stream (`rng`, uint32 [n]; production mode --
+// same distribution, not CPython's Mersenne Twister sequence).
+__device__ __forceinline__ uint32_t pcg32(uint32_t &state) {
+  state = state * 747796405u + 2891336453u;
+  const uint32_t w = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+  return (w >> 22u) ^ w;
+}
+
+template <int A, int M>
+__device__ __forceinline__ void place_items(const LevelHdr &L, const Tables &tb, const int32_t *placement,
+                                            uint32_t *rng, int64_t n, int64_t i, int32_t (&w)[A + M + 2]) {
+  if (L.nscatter == 0) return;  // uniform (compile-time in specialised builds)
+  int pos[M];
+#pragma unroll
+  for (int k = 0; k < M; k++) pos[k] = w[A + k] & 255;
+  if (rng != nullptr) {
+    uint32_t st = rng[i];
+    unsigned long long taken = 0;
+    for (int k = 0; k < (int)L.nscatter; k++) {
+      int idx = 0;
+      bool ok = false;
+      for (int attempt = 0; attempt < 64 && !ok; attempt++) {
+        idx = (int)__umulhi(pcg32(st), L.ncounters);
+        ok = !((taken >> idx) & 1);
+      }
+      for (int c = 0; c < (int)L.ncounters && !ok; c++) {  // practically unreachable
+        idx = c;
+        ok = !((taken >> idx) & 1);
+      }
+      taken |= 1ull << idx;
+      const int cell = tb.counters[idx];
+      const int item = (int)L.scatter_item[k & 3];
+#pragma unroll
+      for (int m = 0; m < M; m++) pos[m] = (item == m) ? cell : pos[m];
+    }
+    rng[i] = st;
+  } else if (placement != nullptr) {
+#pragma unroll
+    for (int k = 0; k < M; k++) pos[k] = placement[(int64_t)k * n + i] & 255;
+  }
+#pragma unroll
+  for (int k = 0; k < M; k++) w[A + k] = (w[A + k] & ~255) | pos[k];
 }
 
 struct StepArgs {
@@ -672,6 +725,8 @@ struct StepArgs {
   int32_t *done;
   double *shaping;
   int64_t *metrics;
+  const int32_t *placement;
+  uint32_t *rng;
   int64_t n;
   int32_t auto_reset;
 };
@@ -712,6 +767,7 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs p) {
     if (done && p.auto_reset) {
 #pragma unroll
       for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
+      place_items<A, M>(L, tb, p.placement, p.rng, p.n, i, w);
     } else {
       pack<A, M>(e, w);
     }
@@ -756,18 +812,31 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
 }
 
 struct ResetArgs {
-  const int32_t *init;
+  LevelHdr L;
+  const void *tables;
+  int32_t n16, quot_bytes;
   int32_t *state;
   const int32_t *mask;
+  const int32_t *placement;
+  uint32_t *rng;
   int64_t n;
-  int32_t words;
 };
 
+// OvercookedEnvironment.reset() (overcooked_environment.py:180-206), masked
+template <int A, int M>
 __global__ void __launch_bounds__(256) k_reset(const ResetArgs p) {
+  const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
   if (p.mask != nullptr && p.mask[i] == 0) return;
-  for (int r = 0; r < p.words; r++) p.state[(int64_t)r * p.n + i] = p.init[r];
+  constexpr int WS = A + M + 2;
+  const Tables tb = stage_tables<false>(p.tables, p.n16, p.quot_bytes);
+  int32_t w[WS];
+#pragma unroll
+  for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
+  place_items<A, M>(L, tb, p.placement, p.rng, p.n, i, w);
+#pragma unroll
+  for (int r = 0; r < WS; r++) p.state[(int64_t)r * p.n + i] = w[r];
 }
 
 struct MultiArgs {
@@ -784,6 +853,8 @@ struct MultiArgs {
   int32_t *done;
   int32_t *sparse;
   int64_t *metrics;
+  const int32_t *placement;
+  uint32_t *rng;
   int64_t n;
   int32_t auto_reset;
   oc_wrap_cfg cfg;
@@ -839,6 +910,7 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
     if (done && p.auto_reset) {
 #pragma unroll
       for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
+      place_items<A, M>(L, tb, p.placement, p.rng, p.n, i, w);
       unpack<A, M>(e, w);
     } else {
       pack<A, M>(e, w);
@@ -1013,6 +1085,15 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
     if (n_groups * h.max_path > kmax) kmax = n_groups * h.max_path;      // pair term numerator
     h.nquot = (uint32_t)(kmax + 2);
   }
+  h.nscatter = (uint32_t)b[OC_LV_NSCATTER];
+  h.ncounters = (uint32_t)b[OC_LV_NCOUNTERS];
+  if (h.nscatter > 4 || h.ncounters > OC_MAX_COUNTERS || (h.nscatter > 0 && h.ncounters < h.nscatter))
+    return "bad scatter / Counter counts";
+  for (uint32_t k = 0; k < h.nscatter; k++) {
+    const int item = (b + b[OC_LV_OFF_SCATTER])[k];
+    if (item < 0 || item >= M) return "bad scatter item index";
+    h.scatter_item[k] = (uint32_t)item;
+  }
   return nullptr;
 }
 
@@ -1067,7 +1148,9 @@ int oc_level_spec_source(const int32_t *b, int32_t n_words, char *buf, int32_t b
   EMIT_ARR(h.deliv_pos, OC_MAX_DELIV);
   EMIT("  {");
   for (int k = 0; k < OC_MAX_AGENTS + OC_MAX_ITEMS + 2; k++) EMIT("%s%d", k ? ", " : "", h.init_words[k]);
-  EMIT("},\n  %uu\n};\n", h.nquot);
+  EMIT("},\n  %uu,\n  %uu, %uu,\n", h.nquot, h.nscatter, h.ncounters);
+  EMIT_ARR(h.scatter_item, 4);
+  EMIT("};\n");
 #undef EMIT_ARR
 #undef EMIT
   if (n >= buf_size) return fail(OC_E_BADARG, "oc_level_spec_source: buffer too small");
@@ -1079,7 +1162,6 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   oc_level *lv = new (std::nothrow) oc_level();
   if (!lv) return fail(OC_E_BADARG, "oc_level_create: out of memory");
   lv->dev_tables = nullptr;
-  lv->dev_init = nullptr;
   LevelHdr &h = lv->hdr;
   const char *msg = build_header(b, n_words, h, lv->run);
   if (msg) {
@@ -1101,7 +1183,8 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   // tables buffer: the quotients k / MAX_PATH for every numerator the shaping formula can
   // form (correctly rounded fp64 division, as CPython's int / int), then the u8 distances
   lv->quot_bytes = (int32_t)(sizeof(double) * h.nquot);
-  const size_t bytes = ((size_t)lv->quot_bytes + (size_t)nc * nc + 15) & ~(size_t)15;
+  // ... then, in the last 64 bytes, the Counter tiles (x | y<<4) for random placement
+  const size_t bytes = (((size_t)lv->quot_bytes + (size_t)nc * nc + 15) & ~(size_t)15) + OC_MAX_COUNTERS;
   lv->n16 = (int32_t)(bytes / 16);
   uint8_t *img = new (std::nothrow) uint8_t[bytes];
   if (!img) {
@@ -1112,11 +1195,14 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   double *quot = (double *)img;
   for (uint32_t k = 0; k < h.nquot; k++) quot[k] = (double)(int)k / (double)h.max_path;
   for (int i = 0; i < nc * nc; i++) img[lv->quot_bytes + i] = (uint8_t)dist[i];
+  {
+    const int32_t *ct = b + b[OC_LV_OFF_COUNTERS];
+    for (int k = 0; k < b[OC_LV_NCOUNTERS]; k++)
+      img[bytes - OC_MAX_COUNTERS + k] = (uint8_t)(ct[2 * k] | (ct[2 * k + 1] << 4));
+  }
   hipError_t e = hipGetDevice(&lv->device);
   if (e == hipSuccess) e = hipMalloc(&lv->dev_tables, bytes);
-  if (e == hipSuccess) e = hipMalloc((void **)&lv->dev_init, sizeof(h.init_words));
   if (e == hipSuccess) e = hipMemcpy(lv->dev_tables, img, bytes, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(lv->dev_init, h.init_words, sizeof(h.init_words), hipMemcpyHostToDevice);
   delete[] img;
   if (e != hipSuccess) {
     oc_level_destroy(lv);
@@ -1130,7 +1216,6 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
 int oc_level_destroy(oc_level_t *lv) {
   if (!lv) return OC_OK;
   if (lv->dev_tables) (void)hipFree(lv->dev_tables);
-  if (lv->dev_init) (void)hipFree(lv->dev_init);
   delete lv;
   return OC_OK;
 }
@@ -1141,25 +1226,31 @@ int32_t oc_obs_rows(const oc_level_t *lv, int32_t num_comm) {
   return lv ? 22 + lv->hdr.S + 2 * num_comm : 0;
 }
 
-int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, int64_t n, void *stream) {
+int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, const int32_t *placement, uint32_t *rng,
+             int64_t n, void *stream) {
   if (lv && n == 0) return OC_OK;
   if (!lv || !state || n < 0) return fail(OC_E_BADARG, "oc_reset: bad argument");
-  ResetArgs a{lv->dev_init, state, mask, n, lv->hdr.A + lv->hdr.M + 2};
-  const int bs = 256;
-  hipLaunchKernelGGL(k_reset, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, (hipStream_t)stream, a);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? OC_OK : fail_hip(e, "oc_reset");
+  if (lv->hdr.nscatter > 0 && !placement && !rng)
+    return fail(OC_E_BADARG, "oc_reset: this level places items at random; pass `placement` or `rng`");
+  ResetArgs a{lv->hdr, lv->dev_tables, lv->n16, lv->quot_bytes, state, mask, placement, rng, n};
+  const int A_ = lv->hdr.A, M_ = lv->hdr.M;
+#define OC_X(AA, MM) return launch(k_reset<AA, MM>, a, n, stream, 0)
+  OC_FOR_AM(OC_X)
+#undef OC_X
 }
 
 int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_t *reward, int32_t *done,
-            double *shaping, int32_t auto_reset, int64_t *metrics, int64_t n, void *stream) {
+            double *shaping, int32_t auto_reset, int64_t *metrics, const int32_t *placement, uint32_t *rng,
+            int64_t n, void *stream) {
   if (lv && n == 0) return OC_OK;
   if (!lv || !state || !actions || !reward || !done || !shaping || n < 0)
     return fail(OC_E_BADARG, "oc_step: bad argument");
   if (!fits_buffer(n, lv->hdr.A + lv->hdr.M + 2, 4) || !fits_buffer(n, 2, 8))
     return fail(OC_E_BADARG, "oc_step: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
+  if (auto_reset && lv->hdr.nscatter > 0 && !placement && !rng)
+    return fail(OC_E_BADARG, "oc_step: auto_reset on a random-placement level needs `placement` or `rng`");
   StepArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, actions, reward, done, shaping,
-             metrics, n, auto_reset};
+             metrics, placement, rng, n, auto_reset};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
   const size_t lds = (size_t)lv->n16 * 16;
   if (tables_in_lds(n)) {
@@ -1189,7 +1280,8 @@ int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, cons
 
 int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
                   const oc_wrap_cfg *cfg, int32_t *obs, double *timestep, double *reward, int32_t *done,
-                  int32_t *sparse, int32_t auto_reset, int64_t *metrics, int64_t n, void *stream) {
+                  int32_t *sparse, int32_t auto_reset, int64_t *metrics, const int32_t *placement, uint32_t *rng,
+                  int64_t n, void *stream) {
   if (lv && cfg && n == 0) return OC_OK;
   if (!lv || !state || !comm || !actions || !cfg || !obs || !timestep || !reward || !done || n < 0 ||
       cfg->obs.num_comm < 0 || cfg->obs.num_comm > 64)
@@ -1198,8 +1290,10 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
     return fail(OC_E_BADARG, "oc_multi_step: the gym_comm wrapper drives exactly 2 agents");
   if (!fits_buffer(n, 2 * (22 + lv->hdr.S + 2 * cfg->obs.num_comm), 4))
     return fail(OC_E_BADARG, "oc_multi_step: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
+  if (auto_reset && lv->hdr.nscatter > 0 && !placement && !rng)
+    return fail(OC_E_BADARG, "oc_multi_step: auto_reset on a random-placement level needs `placement` or `rng`");
   MultiArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, comm, actions, obs, timestep,
-              reward, done, sparse, metrics, n, auto_reset, *cfg};
+              reward, done, sparse, metrics, placement, rng, n, auto_reset, *cfg};
   const size_t lds = (size_t)lv->n16 * 16;
   const bool in_lds = tables_in_lds(n);
 #ifdef OC_SPECIALIZED

@@ -115,9 +115,21 @@ OC_API int64_t oc_metrics_slots(int64_t n);                         /* ceil(n / 
 OC_API int32_t oc_state_words(const oc_level_t *lv);                 /* A + M + 2 */
 OC_API int32_t oc_obs_rows(const oc_level_t *lv, int32_t num_comm);  /* 22 + S + 2C */
 
+/* Random item placement (random-* levels; overcooked_environment.py:157-173 scatters the
+ * level's "plt" items over random Counter tiles at every reset).  Two ways to supply the
+ * start cells of a fresh episode, used by oc_reset and by the auto-reset inside the step
+ * kernels (both NULL is an error for such a level, both ignored for fixed levels):
+ *   placement  int32 [M][n]   x | y<<4 per item (world order): the caller's draw, e.g. the
+ *                             reference's own for parity tests
+ *   rng        uint32 [n]     per-env PCG32 state, advanced in place: the kernel draws
+ *                             distinct Counters uniformly (same distribution as the
+ *                             reference's rejection loop, not CPython's MT sequence)
+ * `rng` wins when both are given. */
+
 /* OvercookedEnvironment.reset() (overcooked_environment.py:180-206) for every env
  * whose mask[n] != 0 (mask NULL = all). */
-OC_API int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, int64_t n, void *stream);
+OC_API int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, const int32_t *placement,
+                    uint32_t *rng, int64_t n, void *stream);
 
 /* OvercookedEnvironment.step() (overcooked_environment.py:211-241): check_collisions
  * (:578-613), execute_navigation -> interact (:615-618, utils/interact.py:4-75),
@@ -131,8 +143,8 @@ OC_API int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, i
  *   tensor then holds the fresh episode; reward/done/shaping are the terminal step's).
  *   metrics  int64 [oc_metrics_slots(n)][8] or NULL */
 OC_API int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_t *reward,
-            int32_t *done, double *shaping, int32_t auto_reset, int64_t *metrics, int64_t n,
-            void *stream);
+            int32_t *done, double *shaping, int32_t auto_reset, int64_t *metrics,
+            const int32_t *placement, uint32_t *rng, int64_t n, void *stream);
 
 /* OvercookedMultiEnv.get_observation2 for both viewers
  * (gym_comm/envs/overcooked_env.py:105-159).
@@ -150,8 +162,8 @@ OC_API int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *com
  *   sparse   int32 [n] or NULL  the unshaped integer reward */
 OC_API int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
                   const oc_wrap_cfg *cfg, int32_t *obs, double *timestep, double *reward,
-                  int32_t *done, int32_t *sparse, int32_t auto_reset, int64_t *metrics, int64_t n,
-                  void *stream);
+                  int32_t *done, int32_t *sparse, int32_t auto_reset, int64_t *metrics,
+                  const int32_t *placement, uint32_t *rng, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

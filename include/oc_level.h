@@ -15,7 +15,7 @@
 #include <stdint.h>
 
 #define OC_LV_MAGIC_VALUE 0x4F434C56 /* 'OCLV' */
-#define OC_LV_VERSION_VALUE 1
+#define OC_LV_VERSION_VALUE 2
 
 /* header word indices */
 enum {
@@ -31,7 +31,9 @@ enum {
   OC_LV_ALLERGIC = 9,   /* bit a set: agent a has CONFIG["ALLERGIC"] */
   OC_LV_NPAIR = 10,     /* length of the pair-term type list (Plate + recipe[0] ingredients) */
   OC_LV_NDELIV = 11,    /* number of Delivery tiles */
-  /* 12..15 reserved */
+  OC_LV_NCOUNTERS = 12, /* number of Counter tiles (targets of random item placement) */
+  OC_LV_NSCATTER = 13,  /* items placed on random Counters at every reset (random-* levels) */
+  /* 14..15 reserved */
   OC_LV_OFF_CELLS = 16,    /* W*H words: cell type, index y*W+x */
   OC_LV_OFF_DIST = 17,     /* (W*H)^2 words: D[a*W*H + b] */
   OC_LV_OFF_AGENTS = 18,   /* A * {x, y} */
@@ -40,7 +42,9 @@ enum {
   OC_LV_OFF_PAIR = 21,     /* NPAIR type ids */
   OC_LV_OFF_DELIV = 22,    /* NDELIV * {x, y}, world order (row-major scan) */
   OC_LV_TOTAL = 23,        /* total words */
-  OC_LV_HEADER_WORDS = 24
+  OC_LV_OFF_COUNTERS = 24, /* NCOUNTERS * {x, y}, world order (row-major scan) */
+  OC_LV_OFF_SCATTER = 25,  /* NSCATTER item indices, in the level file's letter order */
+  OC_LV_HEADER_WORDS = 32
 };
 
 /* cell types (gym_cooking/utils/core.py:66-133) */
@@ -58,6 +62,7 @@ enum { OC_ACT_DOWN = 0, OC_ACT_UP = 1, OC_ACT_LEFT = 2, OC_ACT_RIGHT = 3, OC_ACT
 #define OC_MAX_CELLS 128
 #define OC_MAX_DELIV 8
 #define OC_MAX_PAIR 4
+#define OC_MAX_COUNTERS 64
 
 /* goal_sig: per-type content counts in nibbles: T | L<<4 | O<<8 | P<<12 */
 #define OC_SIG_OF_TYPE(t) (1 << (4 * (t)))

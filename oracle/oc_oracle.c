@@ -71,6 +71,9 @@ typedef struct {
   int goalcnt[OC_MAX_SUBTASKS];
   int err;
   int successful;
+  /* random-* levels: start cell (x | y<<4) of every item for the NEXT reset, -1 = the
+   * blob's default (overcooked_environment.py:157-173 draws them with random.choice) */
+  int next_place[OC_MAX_ITEMS];
 } Env;
 
 static const int NAV_DX[5] = {0, 0, -1, 1, 0};
@@ -204,8 +207,8 @@ static void env_reset(Env *e) {
     e->items[i].type = e->item0[3 * i];
     e->items[i].state = 0;
     Obj *o = &e->objs[e->nobjs];
-    o->x = e->item0[3 * i + 1];
-    o->y = e->item0[3 * i + 2];
+    o->x = e->next_place[i] >= 0 ? (e->next_place[i] & 15) : e->item0[3 * i + 1];
+    o->y = e->next_place[i] >= 0 ? (e->next_place[i] >> 4) : e->item0[3 * i + 2];
     o->is_held = 0;
     o->n = 1;
     o->c[0] = i;
@@ -545,6 +548,7 @@ OC_EXPORT void *oc_oracle_create(const int32_t *blob, int n_words) {
     const int32_t *p = b + b[OC_LV_OFF_SUBTASKS] + 4 * s;
     e->sub[s].kind = p[0]; e->sub[s].sig = p[1]; e->sub[s].food = p[2]; e->sub[s].ncont = p[3];
   }
+  for (int i = 0; i < OC_MAX_ITEMS; i++) e->next_place[i] = -1;
   env_reset(e);
   return e;
 }
@@ -570,6 +574,13 @@ OC_EXPORT void *oc_oracle_clone(const void *h) {
 }
 
 OC_EXPORT void oc_oracle_reset(void *h) { env_reset((Env *)h); }
+
+/* Set the item start cells used by every following reset of this env (packed x | y<<4,
+ * one per item in world order; NULL restores the blob's defaults). */
+OC_EXPORT void oc_oracle_set_placement(void *h, const int32_t *cells) {
+  Env *e = (Env *)h;
+  for (int i = 0; i < e->M; i++) e->next_place[i] = cells ? cells[i] : -1;
+}
 
 /* OvercookedEnvironment.step (overcooked_environment.py:211-241).
  * actions: A codes (0..4).  shaping[2] = agent_0 / agent_1 reward shaping. */
@@ -753,6 +764,15 @@ OC_EXPORT void oc_oracle_batch_snapshot(void **envs, int64_t n, int32_t *items, 
 OC_EXPORT void oc_oracle_batch_reset(void **envs, int64_t n, const int32_t *mask) {
   for (int64_t i = 0; i < n; i++)
     if (!mask || mask[i]) env_reset((Env *)envs[i]);
+}
+
+/* placement: [M][n] packed start cells, read by every env (like the HIP library's
+ * `placement` tensor: the cells an env uses at its next reset / auto-reset) */
+OC_EXPORT void oc_oracle_batch_set_placement(void **envs, int64_t n, const int32_t *placement) {
+  for (int64_t i = 0; i < n; i++) {
+    Env *e = (Env *)envs[i];
+    for (int k = 0; k < e->M; k++) e->next_place[k] = placement ? placement[(int64_t)k * n + i] : -1;
+  }
 }
 
 /* K consecutive wrapper steps over envs [n0, n1) in one call (one call per thread in

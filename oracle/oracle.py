@@ -56,6 +56,8 @@ def lib():
         L.oc_oracle_batch_multi_step.argtypes = (
             [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
              _I32P, _I32P] + [ctypes.c_int] * 7 + [_I32P, _F64P, _F64P, _I32P, ctypes.c_int])
+        L.oc_oracle_set_placement.argtypes = [ctypes.c_void_p, _I32P]
+        L.oc_oracle_batch_set_placement.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, _I32P]
         L.oc_oracle_batch_multi_rollout.argtypes = (
             [ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int64] * 4 + [_I32P, _I32P]
             + [ctypes.c_int] * 7 + [_I32P, _F64P, _F64P, _I32P, ctypes.c_int])
@@ -94,6 +96,14 @@ class OracleEnv:
 
     def reset(self):
         lib().oc_oracle_reset(self._h)
+
+    def set_placement(self, cells):
+        """Packed start cells (x | y<<4 per item, world order) for the following resets."""
+        if cells is None:
+            lib().oc_oracle_set_placement(self._h, None)
+        else:
+            a = np.ascontiguousarray(cells, dtype=np.int32)
+            lib().oc_oracle_set_placement(self._h, _p32(a))
 
     def step(self, actions):
         act = np.ascontiguousarray(actions, dtype=np.int32)
@@ -179,6 +189,15 @@ class OracleBatch:
             mask = np.ascontiguousarray(mask, dtype=np.int32)
             m = _p32(mask)
         lib().oc_oracle_batch_reset(self._handles, self.n, m)
+
+    def set_placement(self, placement):
+        """[M][n] packed start cells used at each env's next reset / auto-reset."""
+        if placement is None:
+            lib().oc_oracle_batch_set_placement(self._handles, self.n, None)
+        else:
+            a = np.ascontiguousarray(placement, dtype=np.int32)
+            assert a.shape == (self.M, self.n)
+            lib().oc_oracle_batch_set_placement(self._handles, self.n, _p32(a))
 
     def snapshot_all(self):
         n, A, M, S = self.n, self.A, self.M, self.S

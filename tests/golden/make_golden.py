@@ -134,12 +134,17 @@ def run_base(level, A, T, tapes, ego_config=None, partner_config=None):
     S = len(env.all_subtasks)
     rec = {k: [] for k in ("actions", "items", "order", "agents", "nobj", "t", "reward",
                            "done", "completed", "goal_count", "shaping", "reset_before",
-                           "tape_id")}
+                           "tape_id", "pl_index")}
     names = [a.name for a in env.sim_agents]
+
+    placements = []
 
     def fresh():
         with H.quiet():
             env.reset()
+        # item start cells of this episode, world order (random-* levels scatter them,
+        # overcooked_environment.py:157-173)
+        placements.append([[o.location[0], o.location[1]] for o in H.world_objects(env)])
         return H.base_items(env)
 
     for tape_id, (kind, spec) in enumerate(tapes):
@@ -180,6 +185,7 @@ def run_base(level, A, T, tapes, ego_config=None, partner_config=None):
             rec["shaping"].append([H.f64_bits(info["agent_0_reward_shaping"]),
                                    H.f64_bits(info["agent_1_reward_shaping"])])
             rec["reset_before"].append(need_reset_flag)
+            rec["pl_index"].append(len(placements) - 1)
             rec["tape_id"].append(tape_id)
             need_reset_flag = 0
             if d:
@@ -202,6 +208,9 @@ def run_base(level, A, T, tapes, ego_config=None, partner_config=None):
         "shaping_bits": np.array(rec["shaping"], dtype=np.uint64),
         "reset_before": np.array(rec["reset_before"], dtype=np.int8),
         "tape_id": np.array(rec["tape_id"], dtype=np.int16),
+        # one row per env.reset() call, in call order (= every step with reset_before == 1)
+        "placements": np.array(placements, dtype=np.int8),
+        "pl_index": np.array(rec["pl_index"], dtype=np.int16),   # row of `placements` in force at step k
     }
     return out, int(np.sum(out["reward"])), int(np.sum(out["done"]))
 
@@ -239,10 +248,12 @@ def run_wrapper(name, level, T, steps, seed, kind="purpose", ego_agent_idx=0, **
                   hashseed=os.environ.get("PYTHONHASHSEED", "unset"))
     rng = random.Random(seed)
     pol = Purposeful(static["cells"], 2, rng, eps=0.15) if kind == "purpose" else None
-    rec = {k: [] for k in ("actions", "ts_bits", "obs", "rew_bits", "done", "reset_before")}
+    rec = {k: [] for k in ("actions", "ts_bits", "obs", "rew_bits", "done", "reset_before", "pl_index")}
+    placements = []
     # the constructor already did multi_reset(); record the obs of a fresh multi_reset
     with H.quiet():
         o0, o1 = env.multi_reset()
+    placements.append([[o.location[0], o.location[1]] for o in H.world_objects(base)])
     t0, v0, tags = flat_obs(o0)
     t1, v1, _ = flat_obs(o1)
     reset_obs = {"ts_bits": [t0, t1], "obs": [v0, v1]}
@@ -271,10 +282,12 @@ def run_wrapper(name, level, T, steps, seed, kind="purpose", ego_agent_idx=0, **
         rec["rew_bits"].append(H.f64_bits(r0))
         rec["done"].append(1 if d else 0)
         rec["reset_before"].append(need_reset_flag)
+        rec["pl_index"].append(len(placements) - 1)
         need_reset_flag = 0
         if d:
             with H.quiet():
                 env.multi_reset()
+            placements.append([[o.location[0], o.location[1]] for o in H.world_objects(base)])
             need_reset_flag = 1
             if pol is not None:
                 pol.plan = [deque(), deque()]
@@ -289,6 +302,8 @@ def run_wrapper(name, level, T, steps, seed, kind="purpose", ego_agent_idx=0, **
         "reset_before": np.array(rec["reset_before"], dtype=np.int8),
         "reset_ts_bits": np.array(reset_obs["ts_bits"], dtype=np.uint64),
         "reset_obs": np.array(reset_obs["obs"], dtype=np.int16),
+        "placements": np.array(placements, dtype=np.int8),
+        "pl_index": np.array(rec["pl_index"], dtype=np.int16),
     }
     return out, int(np.sum(out["done"]))
 
@@ -311,9 +326,48 @@ def run_ascii(level, A, T, script):
     return out
 
 
+def main_random(summary):
+    """random-* levels: items scattered on random Counters at every
+    reset with Python's global `random` (seeded here so the run is repeatable)."""
+    base_jobs = [
+        ("random-open-divider_salad_small", 2, 80, [("rand5", (600, 50)), ("purpose", (2500, 60))]),
+        ("random-open-divider_salad_small_wide", 2, 100, [("purpose", (2500, 61))]),
+        ("random-salad-superwide", 2, 100, [("rand5", (400, 52)), ("purpose", (2500, 62))]),
+        ("random-open-divider_tomato", 3, 80, [("purpose", (2500, 63))]),
+        ("random-full-divider_salad", 2, 80, [("purpose", (1500, 64))]),
+        ("random-open-divider_salad_small_wide_big", 2, 100, [("purpose", (2000, 65))]),
+    ]
+    for level, A, T, tapes in base_jobs:
+        random.seed(1000 + A)
+        out, sr, nd = run_base(level, A, T, tapes)
+        fn = "rbase_%s_a%d.npz" % (level, A)
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["t"])), "sum_reward": sr, "episodes": nd}
+        print(fn, summary[fn], flush=True)
+    wrap_jobs = [
+        ("rsmall_r2", "random-open-divider_salad_small", 80, 2500, 120, {}),
+        ("rsuperwide_c5", "random-salad-superwide", 100, 2000, 121, {"num_communication": 5}),
+        ("rwide_r1", "random-open-divider_salad_small_wide", 100, 2000, 122, {"fow_radius": 1}),
+    ]
+    for name, level, T, steps, seed, kw in wrap_jobs:
+        random.seed(seed)
+        out, nd = run_wrapper(name, level, T, steps, seed, **kw)
+        fn = "rwrap_%s.npz" % name
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["done"])), "episodes": nd}
+        print(fn, summary[fn], flush=True)
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     summary = {}
+    if "--random-only" in sys.argv:
+        with open(os.path.join(HERE, "SUMMARY.json")) as f:
+            summary = json.load(f)
+        main_random(summary)
+        with open(os.path.join(HERE, "SUMMARY.json"), "w") as f:
+            json.dump(summary, f, indent=1, sort_keys=True)
+        return
     asc = [run_ascii("open-divider_tomato", 2, 100, KAT1_TOMATO),
            run_ascii("full-divider_salad", 2, 100, KAT2_SALAD)]
     with open(os.path.join(HERE, "ascii_kat.json"), "w") as f:
@@ -387,6 +441,7 @@ def main():
         summary[fn] = {"steps": int(len(out["done"])), "episodes": nd}
         print(fn, summary[fn], flush=True)
 
+    main_random(summary)
     with open(os.path.join(HERE, "SUMMARY.json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
 

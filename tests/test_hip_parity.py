@@ -14,8 +14,14 @@ from spec_levels import SEEDED_CASES, SPEC_GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-BASE = golden_files("base_")
-WRAP = golden_files("wrap_")
+BASE = golden_files("base_") + golden_files("rbase_")      # rbase_/rwrap_: random-* levels
+WRAP = golden_files("wrap_") + golden_files("rwrap_")
+
+
+def _placement_tensor(lv, cells, n):
+    """One episode's item start cells (fixture row) broadcast to all n envs."""
+    packed = torch.tensor(lv.pack_placement(cells), dtype=torch.int32)
+    return packed.view(-1, 1).repeat(1, n).contiguous().cuda()
 # every fixture on the generic library; a subset also on the per-level specialised one
 BASE_RUNS = [(p, False) for p in BASE] + [(p, True) for p in BASE if os.path.basename(p) in SPEC_GOLDEN]
 WRAP_RUNS = [(p, False) for p in WRAP] + [(p, True) for p in WRAP if os.path.basename(p) in SPEC_GOLDEN]
@@ -39,13 +45,15 @@ def test_base_step_matches_reference_golden(run):
     z, st = load_golden(path)
     lv = compile_for(st)
     n = 96
-    env = _env(lv, n, auto_reset=False, specialize_level=spec)
+    env = _env(lv, n, auto_reset=False, specialize_level=spec, placement_mode="host")
     assert env.kernel_flavour == ("spec" if spec else "generic")
     K = len(z["t"])
     acts = torch.from_numpy(np.repeat(z["actions"].astype(np.int32)[:, :, None], n, axis=2)).cuda()
     hist_state, hist_r, hist_d, hist_s = [], [], [], []
     for k in range(K):
         if z["reset_before"][k]:
+            if lv.random_placement:
+                env.set_placement(_placement_tensor(lv, z["placements"][z["pl_index"][k]], n))
             env.reset()
         r, d, sh = env.step(acts[k])
         hist_state.append(env.state.clone())
@@ -85,8 +93,11 @@ def test_wrapper_matches_reference_golden(run, fused):
     z, st = load_golden(path)
     lv = compile_for(st)
     n = 70
-    env = _wrap_env(st, lv, n, auto_reset=False, specialize_level=spec)
+    env = _wrap_env(st, lv, n, auto_reset=False, specialize_level=spec, placement_mode="host")
     C = st["num_communication"]
+    if lv.random_placement:
+        env.set_placement(_placement_tensor(lv, z["placements"][0], n))
+        env.reset()
     # observation right after multi_reset()
     obs, ts = env.observe()
     obs_h, ts_h = obs.cpu().numpy(), ts.cpu().numpy()
@@ -99,6 +110,8 @@ def test_wrapper_matches_reference_golden(run, fused):
     can = (1 if st["ego_config"]["CAN_MOVE"] else 0) | (2 if st["partner_config"]["CAN_MOVE"] else 0)
     for k in range(K):
         if z["reset_before"][k]:
+            if lv.random_placement:
+                env.set_placement(_placement_tensor(lv, z["placements"][z["pl_index"][k]], n))
             env.reset()
         if fused:
             o, t, r, d = env.multi_step(acts[k])
@@ -190,3 +203,84 @@ def test_multi_step_matches_oracle_seeded(level, T, C, radius, spec, oracle_lib)
         assert np.array_equal(o.cpu().numpy(), oo), ctx
         assert np.array_equal(bits(t.cpu().numpy()), bits(to)), ctx
         assert np.array_equal(env.comm.cpu().numpy(), comm), ctx
+
+
+RANDOM_CASES = [("random-open-divider_salad_small", 2, 80), ("random-salad-superwide", 2, 100),
+                ("random-open-divider_tomato", 3, 80), ("random-partial-divider_salad", 4, 90)]
+
+
+@pytest.mark.parametrize("level,A,T", RANDOM_CASES, ids=["%s-a%d" % (c[0], c[1]) for c in RANDOM_CASES])
+def test_random_levels_match_oracle_with_host_placements(level, A, T, oracle_lib):
+    """random-* levels, every env with its own item placement (host-supplied, so the oracle
+    sees the same draw), auto-reset on: full state compare every step."""
+    from gym_comm_amd import compiler
+    lv = compiler.compile_level(level, A, T)
+    n, steps = 600, 240
+    rng = np.random.default_rng(77 + A)
+    nc = len(lv.counters)
+    place = np.zeros((lv.num_items, n), np.int32)
+    for i in range(n):
+        pick = rng.choice(nc, size=len(lv.scatter_items), replace=False)
+        for k, item in enumerate(lv.scatter_items):
+            x, y = lv.counters[pick[k]]
+            place[item, i] = x | (y << 4)
+    acts = scripted_then_random(rng, level, steps, A, n)
+    ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
+    ora.set_placement(place)
+    ora.reset()
+    env = _env(lv, n, auto_reset=True, placement_mode="host")
+    env.set_placement(torch.from_numpy(place).cuda())
+    env.reset()
+    acts_d = torch.from_numpy(acts).cuda()
+    tot = 0
+    for k in range(steps):
+        r, d, sh = env.step(acts_d[k])
+        ro, do, sho = ora.step(acts[k], auto_reset=True)
+        hs, os_ = env.snapshot(), ora.snapshot_all()
+        clean = (os_["error"] == 0) & (hs["error"] == 0)
+        assert ((os_["error"] != 0) == (hs["error"] != 0)).all(), (level, k)
+        ctx = "%s step %d" % (level, k)
+        assert np.array_equal(r.cpu().numpy()[clean], ro[clean]), ctx
+        assert np.array_equal(d.cpu().numpy()[clean], do[clean]), ctx
+        assert np.array_equal(bits(sh.cpu().numpy())[:, clean], bits(sho)[:, clean]), ctx
+        assert_snapshots_equal(hs, os_, ctx, where=clean)
+        tot += int(r.sum().item())
+    assert tot > 0
+
+
+def test_random_levels_device_rng_placements():
+    """placement_mode='rng': the in-kernel PCG32 draw puts every scattered item on its own
+    Counter tile, uniformly, reproducibly per seed, and re-draws at every auto-reset."""
+    from gym_comm_amd import compiler
+    from gym_comm_amd.state import unpack_state
+    lv = compiler.compile_level("random-open-divider_salad_small", 2, 5)
+    n = 8192
+    counters = {(x, y) for x, y in lv.counters}
+
+    def cells(env):
+        s = unpack_state(env.state.cpu().numpy(), 2, lv.num_items, lv.num_subtasks)
+        return s["items"][:, :, :2]
+
+    a = _env(lv, n, auto_reset=True, seed=5)
+    b = _env(lv, n, auto_reset=True, seed=5)
+    c = _env(lv, n, auto_reset=True, seed=6)
+    ca, cb, cc = cells(a), cells(b), cells(c)
+    assert (ca == cb).all() and not (ca == cc).all()
+    for e in range(0, n, 97):
+        got = [tuple(ca[e, i]) for i in range(lv.num_items)]
+        assert set(got) <= counters and len(set(got)) == lv.num_items
+    # roughly uniform over the 9 Counters
+    hist = np.zeros((7, 7), np.int64)
+    for i in range(lv.num_items):
+        np.add.at(hist, (ca[:, i, 1], ca[:, i, 0]), 1)
+    per = np.array([hist[y, x] for x, y in lv.counters]) / float(n * lv.num_items)
+    assert np.abs(per - 1.0 / len(lv.counters)).max() < 0.02
+    # T = 5: every env times out and is re-placed by the auto-reset
+    acts = torch.full((2, n), 4, dtype=torch.int32, device="cuda")
+    for _ in range(5):
+        a.step(acts)
+    cnew = cells(a)
+    assert (a.done == 1).all() and (cnew != ca).any(axis=(1, 2)).mean() > 0.9
+    for e in range(0, n, 211):
+        got = [tuple(cnew[e, i]) for i in range(lv.num_items)]
+        assert set(got) <= counters and len(set(got)) == lv.num_items

@@ -11,14 +11,15 @@ import pytest
 
 from conftest import ROOT, compile_for, golden_files, load_golden
 
-ALL = golden_files("base_") + golden_files("wrap_")
+ALL = golden_files("base_") + golden_files("wrap_") + golden_files("rbase_") + golden_files("rwrap_")
 
 
 @pytest.mark.parametrize("path", ALL, ids=[os.path.basename(p) for p in ALL])
 def test_level_compiler_matches_reference_static_tables(path):
     from gym_comm_amd import compiler as C, levels as L
     z, st = load_golden(path)
-    lv = C.compile_level(st["level"], st["num_agents"], st["max_num_timesteps"])
+    place = [(x, y) for _, x, y in st["items"]] if st["level"].startswith("random-") else None
+    lv = C.compile_level(st["level"], st["num_agents"], st["max_num_timesteps"], placements=place)
     assert (lv.width, lv.height) == (st["width"], st["height"])
     assert (lv.cells == np.array(st["cells"])).all()
     assert (lv.dist == np.array(st["dist"])).all()          # World.get_path_distance_between, all pairs
@@ -55,10 +56,13 @@ def test_level_errors():
         C.compile_level("no-such-level", 2)
     with pytest.raises(ValueError):
         C.compile_level("open-divider_tomato", 5)
-    with pytest.raises(ValueError):
-        C.compile_level("random-open-divider_salad_small", 2)       # needs placements
+    lv = C.compile_level("random-open-divider_salad_small", 2)      # nominal placement
+    assert lv.random_placement and lv.scatter_items == [0, 1, 2] and len(lv.counters) == 9
+    assert not C.compile_level("open-divider_tomato", 2).random_placement
     lv = C.compile_level("random-open-divider_salad_small", 2, placements=[(1, 0), (4, 1), (3, 4)])
     assert [t for t, _, _ in lv.items] == [3, 1, 0] and lv.num_subtasks == 9
+    with pytest.raises(ValueError):
+        C.compile_level("random-open-divider_salad_small", 2, placements=[(1, 1), (4, 1), (3, 4)])  # Floor
     with pytest.raises(ValueError):
         C.compile_level("open-divider_tomato", 2, subtask_order=[0, 0, 1])
     with pytest.raises(ValueError):
@@ -87,7 +91,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert getattr(L, sym) is not None
     assert L.oc_abi_version() == 1
     # argument validation happens before any device work
-    assert L.oc_step(None, None, None, None, None, None, 0, None, 0, None) == -1
+    assert L.oc_step(None, None, None, None, None, None, 0, None, None, None, 0, None) == -1
     assert b"oc_step" in L.oc_last_error()
     bad = np.zeros(32, np.int32)
     h = ctypes.c_void_p()

@@ -8,8 +8,12 @@ import pytest
 
 from conftest import compile_for, golden_files, load_golden
 
-BASE = golden_files("base_")
-WRAP = golden_files("wrap_")
+BASE = golden_files("base_") + golden_files("rbase_")     # rbase_/rwrap_: random-* levels
+WRAP = golden_files("wrap_") + golden_files("rwrap_")
+
+
+def _pack(cells):
+    return [int(x) | (int(y) << 4) for x, y in cells]
 
 
 def test_fixtures_present():
@@ -25,6 +29,8 @@ def test_base_env_matches_reference(path, oracle_lib):
     sh_bits = z["shaping_bits"]
     for k in range(K):
         if z["reset_before"][k]:
+            if lv.random_placement:
+                env.set_placement(_pack(z["placements"][z["pl_index"][k]]))
             env.reset()
         r, d, sh = env.step(z["actions"][k])
         snap = env.snapshot()
@@ -51,6 +57,9 @@ def test_wrapper_matches_reference(path, oracle_lib):
     can_move = (1 if st["ego_config"]["CAN_MOVE"] else 0) | (2 if st["partner_config"]["CAN_MOVE"] else 0)
     b = oracle_lib.OracleBatch(lv.blob, 1)
     comm = np.zeros((2, 1), np.int32)          # per_agent_communications starts as one-hot(0)
+    if lv.random_placement:
+        b.set_placement(np.array(_pack(z["placements"][0]), np.int32).reshape(-1, 1))
+        b.reset()
     # obs right after multi_reset()
     for v in range(2):
         o, ts = b.obs(0, v, st["fow_radius"], (blind >> v) & 1, blind & 1, C, comm[:, 0])
@@ -59,6 +68,8 @@ def test_wrapper_matches_reference(path, oracle_lib):
     K = len(z["done"])
     for k in range(K):
         if z["reset_before"][k]:
+            if lv.random_placement:
+                b.set_placement(np.array(_pack(z["placements"][z["pl_index"][k]]), np.int32).reshape(-1, 1))
             b.reset()
         act = z["actions"][k].astype(np.int32).reshape(4, 1)
         obs, ts, rew, done = b.multi_step(
