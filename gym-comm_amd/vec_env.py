@@ -1,0 +1,192 @@
+"""Vectorised trainer boundary: N Overcooked envs behind the
+Stable-Baselines3 ``VecEnv`` API, ego-perspective, with the partner policy evaluated on
+the whole batch.
+
+The reference trains on ONE env: ``RecurrentPPO`` wraps ``OvercookedMultiEnv`` in
+``Monitor + DummyVecEnv(1)`` and pantheonrl asks the partner agent for one action per
+step (pantheonrl/common/multiagentenv.py:149-215, trainer.py:87-121).  Here the same
+ego/partner protocol runs on tensors:
+
+    obs_ego = venv.reset()
+    obs_ego, rewards, dones, infos = venv.step(ego_actions)      # ego_actions [n, 2] = (move, comm)
+
+Every ``step`` asks ``partner(obs_partner)`` for the partner's [n, 2] actions on the
+observations it saw after the previous step (SimultaneousEnv semantics,
+multiagentenv.py:395-404), calls the fused ``oc_multi_step`` kernel once, and reports
+``partner.update(rewards, dones)`` if the partner has that method.  Finished envs are
+auto-reset inside the kernel, so -- as with any SB3 VecEnv -- the observation returned for
+a done env is the first observation of its next episode and ``rewards``/``dones`` belong to
+the finished step.  ``infos[i]["terminal_observation"]`` is only filled with
+``terminal_obs=True`` (three launches per step instead of one).
+
+Subclasses ``stable_baselines3.common.vec_env.VecEnv`` when SB3 is importable; otherwise a
+structural stand-in with the same methods.  ``step_tensors`` is the zero-copy variant for
+policies that live on the GPU.
+"""
+import numpy as np
+import torch
+
+from .batched import OBS_KEYS, BatchedOvercooked
+from .envs import _arg, make_spaces
+
+try:                                                    # pragma: no cover - SB3 absent in CI image
+    from stable_baselines3.common.vec_env import VecEnv as _VecEnvBase
+except Exception:
+    class _VecEnvBase:                                  # structural stand-in
+        def __init__(self, num_envs, observation_space, action_space):
+            self.num_envs = num_envs
+            self.observation_space = observation_space
+            self.action_space = action_space
+
+        def step(self, actions):
+            self.step_async(actions)
+            return self.step_wait()
+
+
+# dtype each key has after SB3 copies it into a buffer of the declared space
+# (gym_comm/envs/overcooked_env.py:41-85: Box float32 / Box int64 / MultiBinary int8)
+SPACE_DTYPE = {
+    "timestep": np.float32, "object_encodings_x": np.int64, "object_encodings_y": np.int64,
+    "state_encodings": np.int8, "is_hidden": np.int8, "completed_subtasks": np.int8,
+    "agent1_location": np.float32, "agent2_location": np.float32, "agent_is_holding": np.int8,
+    "agent1_comm": np.int8, "agent2_comm": np.int8,
+}
+
+
+class RandomPartner:
+    """Uniform random partner (move 0..3, comm 0..C-1), generated on the device."""
+
+    def __init__(self, num_comm, seed=0, device="cuda"):
+        self.C = num_comm
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+        self.device = device
+
+    def __call__(self, obs):
+        n = next(iter(obs.values())).shape[0]
+        mv = torch.randint(0, 4, (n,), generator=self.gen, device=self.device, dtype=torch.int32)
+        cm = torch.randint(0, self.C, (n,), generator=self.gen, device=self.device, dtype=torch.int32)
+        return torch.stack([mv, cm], dim=1)
+
+
+class OvercookedVecEnv(_VecEnvBase):
+    def __init__(self, arglist, num_envs, partner=None, device="cuda", terminal_obs=False,
+                 ego_agent_idx=0, subtask_order=None, level_dir=None, seed=0, **batched_kw):
+        if _arg(arglist, "num_agents") != 2:
+            raise ValueError("the gym_comm wrapper drives exactly 2 agents")
+        self.arglist = arglist
+        self.terminal_obs = bool(terminal_obs)
+        self._b = BatchedOvercooked(
+            _arg(arglist, "level"), num_agents=2, num_envs=num_envs,
+            max_num_timesteps=_arg(arglist, "max_num_timesteps", 100),
+            max_num_subtasks=_arg(arglist, "max_num_subtasks", 14),
+            ego_config=dict(_arg(arglist, "ego_config", {}) or {}),
+            partner_config=dict(_arg(arglist, "partner_config", {}) or {}),
+            num_communication=_arg(arglist, "num_communication", 10),
+            communication_on=_arg(arglist, "communication_on", False),
+            ego_led=_arg(arglist, "ego_led", False), fow_radius=_arg(arglist, "fow_radius", 2),
+            ego_agent_idx=ego_agent_idx, device=device, subtask_order=subtask_order,
+            level_dir=level_dir, auto_reset=True, seed=seed, **batched_kw)
+        lv = self._b.level
+        obs_space, act_space = make_spaces(lv.width, lv.height, lv.num_subtasks, self._b.C)
+        super().__init__(num_envs, obs_space, act_space)
+        self.partner = partner if partner is not None else RandomPartner(self._b.C, seed, self._b.device)
+        self._act = torch.zeros((4, num_envs), dtype=torch.int32, device=self._b.device)
+        self._pending = None
+        self._partner_obs = None
+        self.episode_returns = torch.zeros(num_envs, dtype=torch.float64, device=self._b.device)
+        self.episode_lengths = torch.zeros(num_envs, dtype=torch.int64, device=self._b.device)
+
+    # -- tensors ---------------------------------------------------------------------
+    def _obs_tensors(self, viewer):
+        """The 11 keys as [n, k] device tensors (views of the kernel's [k][n] rows)."""
+        d = self._b.obs_dict(viewer)
+        return {k: v.T for k, v in d.items()}
+
+    def reset_tensors(self):
+        self._b.reset()
+        self._b.observe()
+        self.episode_returns.zero_()
+        self.episode_lengths.zero_()
+        self._partner_obs = self._obs_tensors(1)
+        return self._obs_tensors(0)
+
+    def step_tensors(self, ego_actions):
+        """ego_actions: int tensor [n, 2] on the device.  Returns (ego obs dict of [n, k]
+        tensors, shaped reward f64 [n], done int32 [n]) -- views that the next step
+        overwrites."""
+        b = self._b
+        pa = self.partner(self._partner_obs)
+        pa = torch.as_tensor(pa, device=b.device).to(torch.int32)
+        ea = torch.as_tensor(ego_actions, device=b.device).to(torch.int32)
+        self._act[0], self._act[1] = ea[:, 0], ea[:, 1]
+        self._act[2], self._act[3] = pa[:, 0], pa[:, 1]
+        term = None
+        if self.terminal_obs:
+            b.multi_step(self._act, auto_reset=False)
+            term = {k: v.clone() for k, v in self._obs_tensors(0).items()}
+            b.reset(b.done)                                   # mask = done flags
+            b.observe()
+        else:
+            b.multi_step(self._act)
+        rew, done = b.shaped_reward, b.done
+        self.episode_returns += rew
+        self.episode_lengths += 1
+        self._last_terminal = term
+        if hasattr(self.partner, "update"):
+            self.partner.update(rew, done)
+        self._partner_obs = self._obs_tensors(1)
+        return self._obs_tensors(0), rew, done
+
+    # -- SB3 VecEnv API (numpy) --------------------------------------------------------
+    @staticmethod
+    def _to_numpy(obs):
+        return {k: v.cpu().numpy().astype(SPACE_DTYPE[k]) for k, v in obs.items()}
+
+    def reset(self):
+        return self._to_numpy(self.reset_tensors())
+
+    def step_async(self, actions):
+        self._pending = np.asarray(actions)
+
+    def step_wait(self):
+        obs, rew, done = self.step_tensors(torch.from_numpy(self._pending.astype(np.int32)))
+        done_np = done.cpu().numpy().astype(bool)
+        rew_np = rew.cpu().numpy().astype(np.float32)
+        infos = [{} for _ in range(self.num_envs)]
+        idx = np.nonzero(done_np)[0]
+        if len(idx):
+            ret = self.episode_returns.cpu().numpy()
+            ln = self.episode_lengths.cpu().numpy()
+            term = self._to_numpy(self._last_terminal) if self._last_terminal is not None else None
+            for i in idx:
+                infos[i]["episode"] = {"r": float(ret[i]), "l": int(ln[i])}     # Monitor-style
+                if term is not None:
+                    infos[i]["terminal_observation"] = {k: v[i] for k, v in term.items()}
+            m = done.bool()
+            self.episode_returns[m] = 0
+            self.episode_lengths[m] = 0
+        return self._to_numpy(obs), rew_np, done_np, infos
+
+    def close(self):
+        pass
+
+    def seed(self, seed=None):
+        return [seed] * self.num_envs
+
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self, attr_name)] * n
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self, method_name)(*method_args, **method_kwargs)] * n
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [False] * n
+
+    def metrics(self):
+        return self._b.read_metrics()
