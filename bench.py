@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--comm", type=int, default=2)
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--graph-steps", type=int, default=WINDOW)
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N>1 on one GPU)")
+    p.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
@@ -103,6 +105,11 @@ def cpu_baseline(level_blob, A, C, wrapper, seconds):
 
 def main():
     args = parse()
+    # native libraries (RCCL's version banner, gloo's rank chatter) print to fd 1; keep
+    # stdout clean for the ONE JSON line by pointing fd 1 at stderr until we print it
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,12 +117,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     from gym_comm_amd.batched import BatchedOvercooked
     wrapper = args.agents == 2
@@ -195,6 +207,8 @@ def main():
 
     # end-of-rollout metrics: the only collective on the path (RCCL all-gather, 64 B/rank)
     from gym_comm_amd import dist as ocdist
+    if dist is not None and args.backend != "nccl":
+        rollout_metrics = rollout_metrics.cpu()          # gloo rehearsal: gather on host tensors
     g = ocdist.gather_rollout_metrics(rollout_metrics, elapsed)
     elapsed = g["elapsed_s"]
     m = [g["total"][k] for k in ocdist.METRIC_NAMES]
@@ -242,7 +256,10 @@ def main():
                                                args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
