@@ -623,13 +623,14 @@ struct MetricsSlot {
 // ---------------------------------------------------------------------------
 // The two lane-indexed tables (fp64 quotients, then the u8 distance table) sit in one
 // device buffer.  Two variants of every step kernel exist (template bool LDS):
-//   LDS = false  the tables are read straight from global memory (vector L1/L2).  Best
-//                for small batches, where a workgroup is one wave and a staging pass +
-//                barrier is pure added latency (n = 4096: 4.7 us vs 5.7 us per step);
+//   LDS = false  the tables are read straight from global memory (vector L1/L2): no
+//                staging pass, no barrier.  The default: fastest at every batch size with
+//                64- or 128-thread workgroups (n = 4096: 4.7 us vs 5.7 us per step;
+//                n = 131072: 11.1 us vs 12.7 us).
 //   LDS = true   every workgroup copies them to LDS with 16-byte loads issued BEFORE the
-//                state loads, so both round trips overlap.  Best once several waves
-//                share a CU (n = 131072: 11.3 us vs 13.2 us).
-// The launcher picks by batch size.
+//                state loads, so both round trips overlap.  Only ahead with 256-thread
+//                workgroups (n = 131072: 12.1 us vs 13.3 us), which lose overall.
+// Full sweep: profiles/r01_v3_block_lds_sweep.txt.
 struct Tables {
   const double *quot;
   const uint8_t *dist;
@@ -943,10 +944,12 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
 // host side
 // ---------------------------------------------------------------------------
 int block_size_for(int64_t n) {
-  // small batches: one wave per workgroup, so the work spreads over more CUs
+  // One wave per workgroup spreads a batch over the most CUs and measured fastest up to
+  // 131 072 envs (MI355X sweep, profiles/r01_v3_block_lds_sweep.txt); two waves per
+  // workgroup from 262 144 envs on.  OC_BLOCK overrides (tuning / tests).
   static const int forced = getenv("OC_BLOCK") ? atoi(getenv("OC_BLOCK")) : 0;
   if (forced == 64 || forced == 128 || forced == 256) return forced;
-  return n >= 256 * 256 ? 256 : 64;
+  return n >= 4 * 256 * 256 ? 128 : 64;
 }
 
 // rows are addressed with 32-bit byte offsets through a buffer descriptor
@@ -964,10 +967,12 @@ int launch(K kernel, const Args &args, int64_t n, void *stream, size_t lds_bytes
   return OC_OK;
 }
 
-bool tables_in_lds(int64_t n) {
+bool tables_in_lds(int64_t) {
+  // Off by default: with one- or two-wave workgroups the staging pass + barrier never paid
+  // in the sweep (it only wins with 256-thread workgroups, which lose overall).
+  // OC_TABLES_LDS=1 selects the LDS variant (kept compiled, tested, and measured).
   static const int forced = getenv("OC_TABLES_LDS") ? atoi(getenv("OC_TABLES_LDS")) : -1;
-  if (forced == 0 || forced == 1) return forced == 1;
-  return n >= 256 * 256;   // several waves per CU: see stage_tables()
+  return forced == 1;
 }
 
 #ifdef OC_SPECIALIZED

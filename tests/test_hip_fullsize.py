@@ -2,7 +2,7 @@
 in seconds, so full size is checked through a size-independent property: env i is fed the
 action stream of env (i mod 256); the first 256 envs are compared with the oracle bit for
 bit every step, and every other env must equal its residue-class representative (checked
-on the GPU).  Batches >= 65 536 also exercise the LDS-table kernel variant."""
+on the GPU).  The opt-in LDS-table kernel variant is checked in a child process."""
 import numpy as np
 import pytest
 import torch
@@ -130,3 +130,43 @@ def test_masked_reset_and_argument_errors():
     with pytest.raises(OcError):
         BatchedOvercooked(compiler.compile_level("partial-divider_tl", 3, 50), num_envs=8).multi_step(
             torch.zeros((4, 8), dtype=torch.int32, device="cuda"))
+
+
+_LDS_SNIPPET = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from gym_comm_amd import compiler
+from gym_comm_amd.batched import BatchedOvercooked
+from oracle import oracle
+from hip_util import scripted_then_random
+for level, A, spec in (("open-divider_salad", 2, False), ("partial-divider_tl", 3, True)):
+    lv = compiler.compile_level(level, A, 90)
+    n, steps = 1500, 150
+    rng = np.random.default_rng(5)
+    acts = scripted_then_random(rng, level, steps, A, n)
+    ora = oracle.OracleBatch(lv.blob, n, threads=4)
+    env = BatchedOvercooked(lv, num_envs=n, auto_reset=True, specialize_level=spec)
+    a_d = torch.from_numpy(acts).cuda()
+    for k in range(steps):
+        r, d, sh = env.step(a_d[k])
+        ro, do, sho = ora.step(acts[k], auto_reset=True)
+        clean = ora.snapshot_all()["error"] == 0
+        assert np.array_equal(r.cpu().numpy()[clean], ro[clean]), (level, k)
+        assert np.array_equal(d.cpu().numpy()[clean], do[clean]), (level, k)
+        assert np.array_equal(sh.cpu().numpy().view(np.uint64)[:, clean], sho.view(np.uint64)[:, clean]), (level, k)
+print("LDS-variant ok")
+"""
+
+
+def test_lds_table_variant_in_subprocess():
+    """The LDS-staged-table kernel variant (OC_TABLES_LDS=1, 256-thread workgroups) is not
+    the default; it is selected per process, so check it in a child process."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, OC_TABLES_LDS="1", OC_BLOCK="256")
+    out = subprocess.run([sys.executable, "-c", _LDS_SNIPPET % (ROOT, os.path.join(ROOT, "tests"))],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "LDS-variant ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
