@@ -13,7 +13,7 @@ _I32P = ctypes.POINTER(ctypes.c_int32)
 SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destroy",
            "oc_level_spec_source", "oc_is_specialized",
            "oc_metrics_slots", "oc_state_words", "oc_obs_rows", "oc_reset", "oc_step", "oc_obs",
-           "oc_multi_step"]
+           "oc_obs_image", "oc_multi_step"]
 
 
 class ObsCfg(ctypes.Structure):
@@ -67,10 +67,11 @@ def _declare(L):
     L.oc_reset.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, vp]
     L.oc_step.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, ctypes.c_int64, vp]
     L.oc_obs.argtypes = [vp, vp, vp, ctypes.POINTER(ObsCfg), vp, vp, ctypes.c_int64, vp]
+    L.oc_obs_image.argtypes = [vp, vp, ctypes.c_int32, vp, vp, ctypes.c_int64, vp]
     L.oc_multi_step.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
                                 ctypes.c_int32, vp, vp, vp, ctypes.c_int64, vp]
     for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_reset", "oc_step",
-              "oc_obs", "oc_multi_step"):
+              "oc_obs", "oc_obs_image", "oc_multi_step"):
         getattr(L, f).restype = ctypes.c_int
     if L.oc_abi_version() != 1:
         raise OcError("liboc_hip.so ABI version mismatch")

@@ -181,6 +181,28 @@ class BatchedOvercooked:
             self._stream()), "oc_multi_step", self._L)
         return self.obs, self.timestep, self.shaped_reward, self.done
 
+    def observe_image(self, radius: Optional[int] = None):
+        """Image-style fog-of-war observation of both viewers
+        (get_partial_observability_FOW, overcooked_env.py:161-202).  Returns
+        (maps int8 [2][7][W][H][n] -- a view of the kernel's [2][7*W*H][n] rows --,
+        holding int8 [2][n])."""
+        lv = self.level
+        if getattr(self, "_image", None) is None:
+            self._image = torch.zeros((2, 7 * lv.width * lv.height, self.n), dtype=torch.int8,
+                                      device=self.device)
+            self._holding = torch.zeros((2, self.n), dtype=torch.int8, device=self.device)
+        r = self._obs_cfg.fow_radius if radius is None else int(radius)
+        _lib.check(self._L.oc_obs_image(self._h, self._p(self.state), r, self._p(self._image),
+                                        self._p(self._holding), self.n, self._stream()),
+                   "oc_obs_image", self._L)
+        return self._image.view(2, 7, lv.width, lv.height, self.n), self._holding
+
+    def completed_subtasks(self):
+        """completed_subtasks of every env as int32 [S][n] (from the packed state)."""
+        word = self.state[self.A + self.M]
+        bits = torch.arange(self.S, device=self.device, dtype=torch.int32).view(-1, 1)
+        return (word.view(1, -1) >> (16 + bits)) & 1
+
     def obs_dict(self, viewer: int):
         """The 11 observation keys of get_observation2 as tensor views: key -> [k][n]
         (``.T`` gives the [n][k] batch a policy takes); 'timestep' is f64 [1][n]."""

@@ -812,6 +812,67 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
   p.timestep[i] = (double)e.t / (double)p.R.T;  // overcooked_env.py:146
 }
 
+struct ImageArgs {
+  LevelHdr L;
+  const int32_t *state;
+  int8_t *out;        // [2][7*W*H][n]
+  int8_t *holding;    // [2][n]
+  int64_t n;
+  int32_t radius;
+};
+
+// OvercookedMultiEnv.get_partial_observability_FOW for both viewers
+// (gym_comm/envs/overcooked_env.py:161-202; the image-style observation the reference
+// defines but does not call).  Row (k*W + x)*H + y of viewer v holds plane k at cell (x, y)
+// for n consecutive envs (int8, one 64-byte store per wave and row): plane 0 the tile type,
+// planes 1.. "agent i stands here" (:183-185 -- with 3+ agents these overwrite the content
+// planes, as in the reference), planes 3 + channel the contents (Food: state_index + 1,
+// Plate: 1); cells farther than `radius` (manhattan) from the viewer are -1 in every plane.
+template <int A, int M>
+__global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
+  const LevelHdr &L = OC_HDR(p);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  constexpr int WS = A + M + 2;
+  const Rows st(p.state, p.n, WS, i);
+  int32_t w[WS];
+#pragma unroll
+  for (int r = 0; r < WS; r++) w[r] = st.ld(r);
+  Env<A, M> e;
+  unpack<A, M>(e, w);
+  const int W = L.W, H = L.H;
+  const int rows = 7 * W * H;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(2 * rows * p.n), 0x00020000);
+  for (int x = 0; x < W; x++)
+    for (int y = 0; y < H; y++) {
+      const int c = y * W + x, cell = x | (y << 4);
+      int plane[7];
+      plane[0] = bit128(L.cell_lo, c) | (bit128(L.cell_hi, c) << 1);
+#pragma unroll
+      for (int k = 1; k < 7; k++) plane[k] = 0;
+#pragma unroll
+      for (int m = 0; m < M; m++) {  // world order is irrelevant: one writer per (plane, cell) value
+        const int t = item_type(L, m);
+        const int v = t == OC_PLATE ? 1 : e.ist[m] + 1;
+#pragma unroll
+        for (int k = 3; k < 7; k++) plane[k] = (t + 3 == k && e.ip[m] == cell) ? v : plane[k];
+      }
+#pragma unroll
+      for (int a = 0; a < A; a++) plane[a + 1] = e.ap[a] == cell ? 1 : plane[a + 1];
+#pragma unroll
+      for (int v = 0; v < 2; v++) {
+        const bool fog = iabs(x - px(e.ap[v])) + iabs(y - py(e.ap[v])) > p.radius;
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+          __builtin_amdgcn_raw_buffer_store_b8((char)(fog ? -1 : plane[k]), rsrc, (int)i,
+                                               (int)((v * rows + (k * W + x) * H + y) * p.n), 0);
+      }
+    }
+  p.holding[i] = e.ah[0] >= 0;
+  p.holding[p.n + i] = e.ah[1] >= 0;
+}
+
 struct ResetArgs {
   LevelHdr L;
   const void *tables;
@@ -1279,6 +1340,19 @@ int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, cons
   ObsArgs a{lv->hdr, lv->run, state, comm, obs, timestep, n, *cfg};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
 #define OC_X(AA, MM) return launch(k_obs<AA, MM>, a, n, stream, 0)
+  OC_FOR_AM(OC_X)
+#undef OC_X
+}
+
+int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int8_t *out, int8_t *holding,
+                 int64_t n, void *stream) {
+  if (lv && n == 0) return OC_OK;
+  if (!lv || !state || !out || !holding || n < 0) return fail(OC_E_BADARG, "oc_obs_image: bad argument");
+  if (!fits_buffer(n, 2 * 7 * lv->hdr.ncells, 1))
+    return fail(OC_E_BADARG, "oc_obs_image: n too large for one call; split the batch");
+  ImageArgs a{lv->hdr, state, out, holding, n, radius};
+  const int A_ = lv->hdr.A, M_ = lv->hdr.M;
+#define OC_X(AA, MM) return launch(k_obs_image<AA, MM>, a, n, stream, 0)
   OC_FOR_AM(OC_X)
 #undef OC_X
 }

@@ -152,6 +152,13 @@ OC_API int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions,
 OC_API int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, const oc_obs_cfg *cfg,
            int32_t *obs, double *timestep, int64_t n, void *stream);
 
+/* OvercookedMultiEnv.get_partial_observability_FOW for both viewers
+ * (gym_comm/envs/overcooked_env.py:161-202), the image-style fog-of-war observation.
+ *   out      int8 [2][7*W*H][n]  row (k*W + x)*H + y = plane k at cell (x, y); -1 = fogged
+ *   holding  int8 [2][n]         (agent 0 holds, agent 1 holds) */
+OC_API int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int8_t *out,
+                        int8_t *holding, int64_t n, void *stream);
+
 /* OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282) in ONE
  * launch: action decoding + CAN_MOVE gating + comm update (:220-262), the base step,
  * both observations, and the shaped reward (r - s0) - s1 (:282).  2-agent levels only

@@ -797,3 +797,31 @@ OC_EXPORT void oc_oracle_batch_rollout(void **envs, int64_t n0, int64_t n1, int6
     oc_oracle_batch_step(envs, n0, n1, n_stride, actions + k * A * n_stride, reward, done, shaping,
                          auto_reset);
 }
+
+/* OvercookedMultiEnv.get_partial_observability_FOW (gym_comm/envs/overcooked_env.py:161-202):
+ * out[(k*W + x)*H + y], k = 0..6: 0 tile type, 1.. agents, 3 + channel contents; cells
+ * farther than `radius` (manhattan) from the viewer are -1 in every plane.
+ * holding[2] = (agent 0 holds, agent 1 holds). */
+OC_EXPORT void oc_oracle_obs_image(const void *h, int viewer, int radius, int8_t *out, int32_t *holding) {
+  const Env *e = (const Env *)h;
+  const int W = e->W, H = e->H;
+  memset(out, 0, (size_t)7 * W * H);
+  int lst[MAXOBJ * 2];
+  int n = world_list(e, lst);
+  for (int i = 0; i < n; i++) { /* :171-178 */
+    const Obj *o = &e->objs[lst[i]];
+    for (int c = 0; c < o->n; c++) {
+      const Item *it = &e->items[o->c[c]];
+      out[((it->type + 3) * W + o->x) * H + o->y] = (int8_t)(it->type == OC_PLATE ? 1 : it->state + 1);
+    }
+  }
+  for (int y = 0; y < H; y++) /* :179-180 */
+    for (int x = 0; x < W; x++) out[(0 * W + x) * H + y] = (int8_t)cell_at(e, x, y);
+  for (int a = 0; a < e->A; a++) out[((a + 1) * W + e->ax[a]) * H + e->ay[a]] = 1; /* :183-185 */
+  for (int x = 0; x < W; x++) /* :187-194 */
+    for (int y = 0; y < H; y++)
+      if (iabs(x - e->ax[viewer]) + iabs(y - e->ay[viewer]) > radius)
+        for (int k = 0; k < 7; k++) out[(k * W + x) * H + y] = -1;
+  holding[0] = e->ahold[0] >= 0;
+  holding[1] = e->ahold[1] >= 0;
+}

@@ -56,6 +56,8 @@ def lib():
         L.oc_oracle_batch_multi_step.argtypes = (
             [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
              _I32P, _I32P] + [ctypes.c_int] * 7 + [_I32P, _F64P, _F64P, _I32P, ctypes.c_int])
+        L.oc_oracle_obs_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_int8), _I32P]
         L.oc_oracle_set_placement.argtypes = [ctypes.c_void_p, _I32P]
         L.oc_oracle_batch_set_placement.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, _I32P]
         L.oc_oracle_batch_multi_rollout.argtypes = (
@@ -96,6 +98,14 @@ class OracleEnv:
 
     def reset(self):
         lib().oc_oracle_reset(self._h)
+
+    def obs_image(self, viewer, radius):
+        W, H = int(self.blob[2]), int(self.blob[3])
+        out = np.zeros((7, W, H), np.int8)
+        hold = np.zeros(2, np.int32)
+        lib().oc_oracle_obs_image(self._h, viewer, radius,
+                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)), _p32(hold))
+        return out, hold
 
     def set_placement(self, cells):
         """Packed start cells (x | y<<4 per item, world order) for the following resets."""

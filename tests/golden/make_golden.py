@@ -326,6 +326,57 @@ def run_ascii(level, A, T, script):
     return out
 
 
+def run_fow(level, T, steps, seed, radius):
+    """OvercookedMultiEnv.get_partial_observability_FOW (overcooked_env.py:161-202; not called
+    by the reference's live code) for both viewers along a goal-directed tape."""
+    arg = H.make_arglist(level, 2, T)
+    env = H.wrapper_env(arg)
+    base = env.base_env
+    static = H.static_tables(base)
+    static.update(level=level, num_agents=2, max_num_timesteps=T, radius=radius,
+                  ego_config=arg.ego_config, partner_config=arg.partner_config,
+                  hashseed=os.environ.get("PYTHONHASHSEED", "unset"))
+    rng = random.Random(seed)
+    pol = Purposeful(static["cells"], 2, rng, eps=0.1)
+    names = [a.name for a in base.sim_agents]
+    rec = {k: [] for k in ("actions", "maps", "holding", "completed", "reset_before")}
+    with H.quiet():
+        base.reset()
+    flag = 1
+
+    def grab():
+        out = []
+        for v in range(2):
+            with H.quiet():
+                o = env.get_partial_observability_FOW(v, radius=radius)
+            out.append(o)
+        rec["maps"].append([np.asarray(o["blockworld_map"]) for o in out])
+        assert (out[0]["agent_is_holding"] == out[1]["agent_is_holding"]).all()
+        rec["holding"].append([int(x) for x in out[0]["agent_is_holding"]])
+        rec["completed"].append([int(x) for x in out[0]["completed_subtasks"]])
+
+    for k in range(steps):
+        acts = [pol.act(base, 0), pol.act(base, 1)]
+        with H.quiet():
+            r, d, info = base.step({n: NAV[a] for n, a in zip(names, acts)})
+        rec["actions"].append(acts)
+        rec["reset_before"].append(flag)
+        flag = 0
+        grab()
+        if d:
+            with H.quiet():
+                base.reset()
+            pol.plan = [deque(), deque()]
+            flag = 1
+    out = {"static_json": np.array(json.dumps(static)),
+           "actions": np.array(rec["actions"], dtype=np.int8),
+           "maps": np.array(rec["maps"], dtype=np.int8),          # [K][2][7][X][Y]
+           "holding": np.array(rec["holding"], dtype=np.int8),
+           "completed": np.array(rec["completed"], dtype=np.int8),
+           "reset_before": np.array(rec["reset_before"], dtype=np.int8)}
+    return out
+
+
 def main_random(summary):
     """random-* levels: items scattered on random Counters at every
     reset with Python's global `random` (seeded here so the run is repeatable)."""
@@ -361,6 +412,13 @@ def main_random(summary):
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     summary = {}
+    if "--fow-only" in sys.argv:
+        for name, level, radius, seed in (("tomato_r2", "open-divider_tomato", 2, 300),
+                                          ("salad_r3", "full-divider_salad", 3, 301)):
+            out = run_fow(level, 100, 1500, seed, radius)
+            np.savez_compressed(os.path.join(HERE, "fow_%s.npz" % name), **out)
+            print("fow_%s.npz" % name, out["maps"].shape, int(out["completed"].sum()))
+        return
     if "--random-only" in sys.argv:
         with open(os.path.join(HERE, "SUMMARY.json")) as f:
             summary = json.load(f)

@@ -14,7 +14,8 @@ SEEDED_CASES = [
 SPEC_GOLDEN = ["base_open-divider_tomato_a2.npz", "base_full-divider_salad_a2.npz",
                "base_partial-divider_tl_a3.npz", "base_full-divider_tl_a4.npz",
                "wrap_tomato_r2.npz", "wrap_salad_open_c5.npz", "wrap_tl_full_blind_allergic.npz",
-               "rbase_random-open-divider_salad_small_a2.npz", "rwrap_rsuperwide_c5.npz"]
+               "rbase_random-open-divider_salad_small_a2.npz", "rwrap_rsuperwide_c5.npz",
+               "fow_tomato_r2.npz", "fow_salad_r3.npz"]
 
 
 def all_spec_levels():

@@ -284,3 +284,28 @@ def test_random_levels_device_rng_placements():
     for e in range(0, n, 211):
         got = [tuple(cnew[e, i]) for i in range(lv.num_items)]
         assert set(got) <= counters and len(set(got)) == lv.num_items
+
+
+FOW = golden_files("fow_")
+
+
+@pytest.mark.parametrize("spec", [False, True], ids=["generic", "spec"])
+@pytest.mark.parametrize("path", FOW, ids=[os.path.basename(p) for p in FOW])
+def test_fow_image_obs_matches_reference_golden(path, spec):
+    """get_partial_observability_FOW (overcooked_env.py:161-202) through oc_obs_image."""
+    z, st = load_golden(path)
+    lv = compile_for(st)
+    n = 80
+    env = _env(lv, n, auto_reset=False, specialize_level=spec, fow_radius=st["radius"])
+    K = 600
+    acts = torch.from_numpy(np.repeat(z["actions"][:K].astype(np.int32)[:, :, None], n, axis=2)).cuda()
+    for k in range(K):
+        if z["reset_before"][k]:
+            env.reset()
+        env.step(acts[k])
+        maps, hold = env.observe_image()
+        m = maps.cpu().numpy()                            # [2][7][W][H][n]
+        for lane in (0, 63, 79):
+            assert (m[..., lane] == z["maps"][k]).all(), (k, lane)
+        assert (hold.cpu().numpy() == z["holding"][k][:, None]).all(), k
+        assert (env.completed_subtasks().cpu().numpy() == z["completed"][k][:, None]).all(), k

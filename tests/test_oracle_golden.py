@@ -81,3 +81,22 @@ def test_wrapper_matches_reference(path, oracle_lib):
         for v in range(2):
             assert (obs[v, :, 0] == z["obs"][k][v]).all(), (ctx, v, obs[v, :, 0], z["obs"][k][v])
             assert ts.view(np.uint64)[0] == z["ts_bits"][k][v], ctx
+
+
+FOW = golden_files("fow_")
+
+
+@pytest.mark.parametrize("path", FOW, ids=[os.path.basename(p) for p in FOW])
+def test_fow_image_obs_matches_reference(path, oracle_lib):
+    z, st = load_golden(path)
+    lv = compile_for(st)
+    env = oracle_lib.OracleEnv(lv.blob)
+    for k in range(len(z["actions"])):
+        if z["reset_before"][k]:
+            env.reset()
+        env.step(z["actions"][k])
+        for v in range(2):
+            img, hold = env.obs_image(v, st["radius"])
+            assert (img == z["maps"][k][v]).all(), (k, v)
+            assert (hold == z["holding"][k]).all(), (k, v)
+        assert (env.snapshot()["completed"] == z["completed"][k]).all()
