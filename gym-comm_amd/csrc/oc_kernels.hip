@@ -212,6 +212,161 @@ struct Rows {
   }
 };
 
+// calculate_reward_shaping for sim agents 0 and 1 (overcooked_environment.py:272-397),
+// given the agents' cells, the item cells, the completed flags and, per Deliver subtask, the
+// cell of its (all-chopped) object if one exists.  The int/int divisions of the reference
+// are entries of the quotient table k / MAX_PATH; sums run left to right in fp64.
+template <int B, int M>
+__device__ __forceinline__ void shaping_terms(const LevelHdr &L, const uint8_t *__restrict__ dist,
+                                              const double *__restrict__ quot, const int (&ap)[B],
+                                              const int (&ipos)[M], int completed,
+                                              const int (&del_has)[MAX_DELS], const int (&del_p)[MAX_DELS],
+                                              double &s0, double &s1 OC_STAMP_PARAM) {
+  const int MAXP = L.max_path;
+  const int nc = L.ncells;
+  int arow[B];
+#pragma unroll
+  for (int b = 0; b < B; b++) arow[b] = dense(L, ap[b]) * nc;
+  int ic[M];
+#pragma unroll
+  for (int i = 0; i < M; i++) ic[i] = dense(L, ipos[i]);
+
+  // issue every distance lookup first, consume afterwards
+  int d_chop[3][B];
+#pragma unroll
+  for (int f = 0; f < 3; f++) {
+#pragma unroll
+    for (int b = 0; b < B; b++) d_chop[f][b] = 0;
+    if (L.chop_mask[f] != 0) {  // uniform
+      int fc = 0;
+#pragma unroll
+      for (int i = 0; i < M; i++) fc = ((int)L.food_item[f] == i) ? ic[i] : fc;
+#pragma unroll
+      for (int b = 0; b < B; b++) d_chop[f][b] = dist[arow[b] + fc];
+    }
+  }
+  int d_pair[MAX_PAIRLK];
+#pragma unroll
+  for (int k = 0; k < MAX_PAIRLK; k++) {
+    d_pair[k] = 0;
+    if (k < (int)L.npairlk) {  // uniform
+      const int li = L.pairlk[k] & 15, lj = (L.pairlk[k] >> 4) & 15;
+      int ci = 0, cj = 0;
+#pragma unroll
+      for (int i = 0; i < M; i++) {
+        ci = (li == i) ? ic[i] : ci;
+        cj = (lj == i) ? ic[i] : cj;
+      }
+      d_pair[k] = dist[ci * nc + cj];
+    }
+  }
+  int d_del[MAX_DELS][B];
+#pragma unroll
+  for (int k = 0; k < MAX_DELS; k++) {
+#pragma unroll
+    for (int b = 0; b < B; b++) d_del[k][b] = 0;
+    if (k < (int)L.ndel) {  // uniform
+      const int mc = dense(L, del_p[k]);
+#pragma unroll
+      for (int b = 0; b < B; b++) d_del[k][b] = dist[arow[b] + mc];
+    }
+  }
+  int d_tile[B];  // min over Delivery tiles of path distance + manhattan (:382-388)
+#pragma unroll
+  for (int b = 0; b < B; b++) d_tile[b] = 1 << 20;
+#pragma unroll
+  for (int k = 0; k < OC_MAX_DELIV; k++)
+    if (k < (int)L.ndeliv) {  // uniform
+      const int dp = (int)L.deliv_pos[k];
+      const int dc = dense(L, dp);
+#pragma unroll
+      for (int b = 0; b < B; b++) d_tile[b] = min(d_tile[b], (int)dist[arow[b] + dc] + manhattan(ap[b], dp));
+    }
+
+  OC_STAMP(3);   // distance lookups issued
+  // Chop term (:278-304)
+  int nchop = 0;
+  int mind[B];
+#pragma unroll
+  for (int b = 0; b < B; b++) mind[b] = 1 << 20;
+#pragma unroll
+  for (int f = 0; f < 3; f++)
+    if (L.chop_mask[f] != 0) {  // uniform
+      const int open = __popc((int)L.chop_mask[f] & ~completed);
+      nchop += open;
+#pragma unroll
+      for (int b = 0; b < B; b++) mind[b] = open ? min(mind[b], d_chop[f][b]) : mind[b];
+    }
+  // pair term (:319-363): agent independent
+  int npairs = (int)L.pair_static_max;
+  int minpair = npairs ? MAXP : (1 << 20);
+  {
+    int cur = MAXP;
+#pragma unroll
+    for (int k = 0; k < MAX_PAIRLK; k++)
+      if (k < (int)L.npairlk) {  // uniform
+        cur = min(cur, d_pair[k]);
+        if ((L.pairlk[k] >> 8) & 1) {  // uniform: last lookup of this name pair
+          const bool keep = cur != 0;    // a zero distance is not appended (:351-352)
+          npairs += keep ? 1 : 0;
+          minpair = keep ? min(minpair, cur) : minpair;
+          cur = MAXP;
+        }
+      }
+  }
+  // the quotients
+  int kq_chop[B], kq_pair;
+#pragma unroll
+  for (int b = 0; b < B; b++) kq_chop[b] = nchop ? (mind[b] + MAXP) + (nchop - 1) * 2 * MAXP : 0;
+  kq_pair = nchop ? npairs * MAXP : (npairs ? minpair + (npairs - 1) * MAXP : 0);
+  int kq_del[MAX_DELS][B];
+  bool del_direct[MAX_DELS][B];
+#pragma unroll
+  for (int k = 0; k < MAX_DELS; k++)
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      kq_del[k][b] = 0;
+      del_direct[k][b] = false;
+      if (k < (int)L.ndel) {
+        const int d = d_del[k][b] + manhattan(ap[b], del_p[k]);
+        del_direct[k][b] = d == 0;                 // the agent holds it (:381)
+        kq_del[k][b] = d == 0 ? d_tile[b] : d;
+      }
+    }
+  OC_STAMP(4);   // distances consumed
+  const int qmax = (int)L.nquot - 1;
+  double q_chop[B], q_pair, q_del[MAX_DELS][B];
+#pragma unroll
+  for (int b = 0; b < B; b++) q_chop[b] = quot[min(kq_chop[b], qmax)];
+  q_pair = quot[min(kq_pair, qmax)];
+#pragma unroll
+  for (int k = 0; k < MAX_DELS; k++)
+#pragma unroll
+    for (int b = 0; b < B; b++) q_del[k][b] = (k < (int)L.ndel) ? quot[min(kq_del[k][b], qmax)] : 0.0;
+
+  OC_STAMP(5);   // quotient loads issued
+  double tot[B];
+#pragma unroll
+  for (int b = 0; b < B; b++) {
+    tot[b] = 0.0;
+    if (nchop) tot[b] += q_chop[b];
+    if (npairs) tot[b] += q_pair;
+  }
+#pragma unroll
+  for (int k = 0; k < MAX_DELS; k++)
+    if (k < (int)L.ndel) {  // uniform; Deliver term in subtask order (:370-395)
+      const bool open = !((completed >> L.del_bit[k]) & 1);
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const double add = !del_has[k] ? 2.0 : (del_direct[k][b] ? q_del[k][b] : q_del[k][b] + 1.0);
+        tot[b] = open ? tot[b] + add : tot[b];
+      }
+    }
+  s0 = tot[0];
+  s1 = B > 1 ? tot[1] : 0.0;
+  OC_STAMP(6);   // shaping done
+}
+
 // ---------------------------------------------------------------------------
 // one environment tick: OvercookedEnvironment.step
 // (gym_cooking/envs/overcooked_environment.py:211-241)
@@ -363,56 +518,16 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   success = (!timeout && all_delivered) ? 1 : 0;
 
   // ---- calculate_reward_shaping for sim agents 0 and 1 (:272-397) ------------
-  // int/int divisions of the reference = entries of the quotient table k / MAX_PATH;
-  // sums run left to right in fp64.
-  const int MAXP = L.max_path;
-  const int nc = L.ncells;
   constexpr int B = A < 2 ? A : 2;
-  int arow[B];
+  int apb[B];
 #pragma unroll
-  for (int b = 0; b < B; b++) arow[b] = dense(L, e.ap[b]) * nc;
-  int ic[M];
-#pragma unroll
-  for (int i = 0; i < M; i++) ic[i] = dense(L, e.ip[i]);
-
-  // issue every distance lookup first, consume afterwards
-  int d_chop[3][B];
-#pragma unroll
-  for (int f = 0; f < 3; f++) {
-#pragma unroll
-    for (int b = 0; b < B; b++) d_chop[f][b] = 0;
-    if (L.chop_mask[f] != 0) {  // uniform
-      int fc = 0;
-#pragma unroll
-      for (int i = 0; i < M; i++) fc = ((int)L.food_item[f] == i) ? ic[i] : fc;
-#pragma unroll
-      for (int b = 0; b < B; b++) d_chop[f][b] = dist[arow[b] + fc];
-    }
-  }
-  int d_pair[MAX_PAIRLK];
-#pragma unroll
-  for (int k = 0; k < MAX_PAIRLK; k++) {
-    d_pair[k] = 0;
-    if (k < (int)L.npairlk) {  // uniform
-      const int li = L.pairlk[k] & 15, lj = (L.pairlk[k] >> 4) & 15;
-      int ci = 0, cj = 0;
-#pragma unroll
-      for (int i = 0; i < M; i++) {
-        ci = (li == i) ? ic[i] : ci;
-        cj = (lj == i) ? ic[i] : cj;
-      }
-      d_pair[k] = dist[ci * nc + cj];
-    }
-  }
-  int del_has[MAX_DELS], del_p[MAX_DELS], d_del[MAX_DELS][B];
+  for (int b = 0; b < B; b++) apb[b] = e.ap[b];
+  int del_has[MAX_DELS], del_p[MAX_DELS];
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++) {
     del_has[k] = 0;
     del_p[k] = 0;
-#pragma unroll
-    for (int b = 0; b < B; b++) d_del[k][b] = 0;
     if (k < (int)L.ndel) {  // uniform
-      int mc = 0;
 #pragma unroll
       for (int i = 0; i < M; i++) {
         const int tb = 1 << item_type(L, i);
@@ -420,106 +535,10 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
                         (e.its[i] != tb || item_type(L, i) == OC_PLATE || e.ist[i]);
         del_has[k] |= ok;
         del_p[k] = ok ? e.ip[i] : del_p[k];
-        mc = ok ? ic[i] : mc;
       }
-#pragma unroll
-      for (int b = 0; b < B; b++) d_del[k][b] = dist[arow[b] + mc];
     }
   }
-  int d_tile[B];  // min over Delivery tiles of path distance + manhattan (:382-388)
-#pragma unroll
-  for (int b = 0; b < B; b++) d_tile[b] = 1 << 20;
-#pragma unroll
-  for (int k = 0; k < OC_MAX_DELIV; k++)
-    if (k < (int)L.ndeliv) {  // uniform
-      const int dp = (int)L.deliv_pos[k];
-      const int dc = dense(L, dp);
-#pragma unroll
-      for (int b = 0; b < B; b++) d_tile[b] = min(d_tile[b], (int)dist[arow[b] + dc] + manhattan(e.ap[b], dp));
-    }
-
-  OC_STAMP(3);   // distance lookups issued
-  // Chop term (:278-304)
-  int nchop = 0;
-  int mind[B];
-#pragma unroll
-  for (int b = 0; b < B; b++) mind[b] = 1 << 20;
-#pragma unroll
-  for (int f = 0; f < 3; f++)
-    if (L.chop_mask[f] != 0) {  // uniform
-      const int open = __popc((int)L.chop_mask[f] & ~e.completed);
-      nchop += open;
-#pragma unroll
-      for (int b = 0; b < B; b++) mind[b] = open ? min(mind[b], d_chop[f][b]) : mind[b];
-    }
-  // pair term (:319-363): agent independent
-  int npairs = (int)L.pair_static_max;
-  int minpair = npairs ? MAXP : (1 << 20);
-  {
-    int cur = MAXP;
-#pragma unroll
-    for (int k = 0; k < MAX_PAIRLK; k++)
-      if (k < (int)L.npairlk) {  // uniform
-        cur = min(cur, d_pair[k]);
-        if ((L.pairlk[k] >> 8) & 1) {  // uniform: last lookup of this name pair
-          const bool keep = cur != 0;    // a zero distance is not appended (:351-352)
-          npairs += keep ? 1 : 0;
-          minpair = keep ? min(minpair, cur) : minpair;
-          cur = MAXP;
-        }
-      }
-  }
-  // the quotients
-  int kq_chop[B], kq_pair;
-#pragma unroll
-  for (int b = 0; b < B; b++) kq_chop[b] = nchop ? (mind[b] + MAXP) + (nchop - 1) * 2 * MAXP : 0;
-  kq_pair = nchop ? npairs * MAXP : (npairs ? minpair + (npairs - 1) * MAXP : 0);
-  int kq_del[MAX_DELS][B];
-  bool del_direct[MAX_DELS][B];
-#pragma unroll
-  for (int k = 0; k < MAX_DELS; k++)
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-      kq_del[k][b] = 0;
-      del_direct[k][b] = false;
-      if (k < (int)L.ndel) {
-        const int d = d_del[k][b] + manhattan(e.ap[b], del_p[k]);
-        del_direct[k][b] = d == 0;                 // the agent holds it (:381)
-        kq_del[k][b] = d == 0 ? d_tile[b] : d;
-      }
-    }
-  OC_STAMP(4);   // distances consumed
-  const int qmax = (int)L.nquot - 1;
-  double q_chop[B], q_pair, q_del[MAX_DELS][B];
-#pragma unroll
-  for (int b = 0; b < B; b++) q_chop[b] = quot[min(kq_chop[b], qmax)];
-  q_pair = quot[min(kq_pair, qmax)];
-#pragma unroll
-  for (int k = 0; k < MAX_DELS; k++)
-#pragma unroll
-    for (int b = 0; b < B; b++) q_del[k][b] = (k < (int)L.ndel) ? quot[min(kq_del[k][b], qmax)] : 0.0;
-
-  OC_STAMP(5);   // quotient loads issued
-  double tot[B];
-#pragma unroll
-  for (int b = 0; b < B; b++) {
-    tot[b] = 0.0;
-    if (nchop) tot[b] += q_chop[b];
-    if (npairs) tot[b] += q_pair;
-  }
-#pragma unroll
-  for (int k = 0; k < MAX_DELS; k++)
-    if (k < (int)L.ndel) {  // uniform; Deliver term in subtask order (:370-395)
-      const bool open = !((e.completed >> L.del_bit[k]) & 1);
-#pragma unroll
-      for (int b = 0; b < B; b++) {
-        const double add = !del_has[k] ? 2.0 : (del_direct[k][b] ? q_del[k][b] : q_del[k][b] + 1.0);
-        tot[b] = open ? tot[b] + add : tot[b];
-      }
-    }
-  s0 = tot[0];
-  s1 = B > 1 ? tot[1] : 0.0;
-  OC_STAMP(6);   // shaping done
+  shaping_terms<B, M>(L, dist, quot, apb, e.ip, e.completed, del_has, del_p, s0, s1 OC_STAMP_PASS);
 }
 
 // get_observation2 (gym_comm/envs/overcooked_env.py:105-159) for one viewer;
@@ -593,9 +612,10 @@ __device__ __forceinline__ int wave_sum_small(int v) {
 struct MetricsSlot {
   int64_t *p;
   int64_t old;
-  __device__ __forceinline__ MetricsSlot(int64_t *metrics, int64_t env_index) {
+  // thread_index: global thread id; one slot per wave
+  __device__ __forceinline__ MetricsSlot(int64_t *metrics, int64_t thread_index) {
     const int lane = threadIdx.x & 63;
-    p = (metrics != nullptr && lane < 6) ? metrics + (env_index >> 6) * OC_MET_COUNT + lane : nullptr;
+    p = (metrics != nullptr && lane < 6) ? metrics + (thread_index >> 6) * OC_MET_COUNT + lane : nullptr;
     old = p ? *p : 0;
   }
   __device__ __forceinline__ void add(bool has_metrics, bool valid, int done, int success, int reward,
