@@ -70,11 +70,13 @@ class RandomPartner:
 
 class OvercookedVecEnv(_VecEnvBase):
     def __init__(self, arglist, num_envs, partner=None, device="cuda", terminal_obs=False,
-                 ego_agent_idx=0, subtask_order=None, level_dir=None, seed=0, **batched_kw):
+                 ego_agent_idx=0, subtask_order=None, level_dir=None, seed=0,
+                 track_episode_stats=True, **batched_kw):
         if _arg(arglist, "num_agents") != 2:
             raise ValueError("the gym_comm wrapper drives exactly 2 agents")
         self.arglist = arglist
         self.terminal_obs = bool(terminal_obs)
+        self.track_episode_stats = bool(track_episode_stats)
         self._b = BatchedOvercooked(
             _arg(arglist, "level"), num_agents=2, num_envs=num_envs,
             max_num_timesteps=_arg(arglist, "max_num_timesteps", 100),
@@ -118,8 +120,7 @@ class OvercookedVecEnv(_VecEnvBase):
         pa = self.partner(self._partner_obs)
         pa = torch.as_tensor(pa, device=b.device).to(torch.int32)
         ea = torch.as_tensor(ego_actions, device=b.device).to(torch.int32)
-        self._act[0], self._act[1] = ea[:, 0], ea[:, 1]
-        self._act[2], self._act[3] = pa[:, 0], pa[:, 1]
+        torch.cat((ea.T, pa.T), dim=0, out=self._act)        # rows: ego move, ego comm, alt move, alt comm
         term = None
         if self.terminal_obs:
             b.multi_step(self._act, auto_reset=False)
@@ -129,8 +130,9 @@ class OvercookedVecEnv(_VecEnvBase):
         else:
             b.multi_step(self._act)
         rew, done = b.shaped_reward, b.done
-        self.episode_returns += rew
-        self.episode_lengths += 1
+        if self.track_episode_stats:
+            self.episode_returns += rew
+            self.episode_lengths += 1
         self._last_terminal = term
         if hasattr(self.partner, "update"):
             self.partner.update(rew, done)
@@ -142,8 +144,19 @@ class OvercookedVecEnv(_VecEnvBase):
     def _to_numpy(obs):
         return {k: v.cpu().numpy().astype(SPACE_DTYPE[k]) for k, v in obs.items()}
 
+    def _ego_obs_numpy(self):
+        """The ego viewer's 11 keys on the host: the [F][n] rows are transposed on the GPU
+        and cross PCIe in ONE copy (plus the fp64 timestep row), then numpy column slices."""
+        b = self._b
+        rows = b.obs[0].T.contiguous().cpu().numpy()        # [n][F] int32
+        out = {"timestep": b.timestep.cpu().numpy().astype(np.float32).reshape(-1, 1)}
+        for k, (lo, hi) in b._layout.items():
+            out[k] = rows[:, lo:hi].astype(SPACE_DTYPE[k])
+        return out
+
     def reset(self):
-        return self._to_numpy(self.reset_tensors())
+        self.reset_tensors()
+        return self._ego_obs_numpy()
 
     def step_async(self, actions):
         self._pending = np.asarray(actions)
@@ -165,7 +178,7 @@ class OvercookedVecEnv(_VecEnvBase):
             m = done.bool()
             self.episode_returns[m] = 0
             self.episode_lengths[m] = 0
-        return self._to_numpy(obs), rew_np, done_np, infos
+        return self._ego_obs_numpy(), rew_np, done_np, infos
 
     def close(self):
         pass
