@@ -14,11 +14,15 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liboc_oracle.so")
+# OC_ORACLE_LIB selects another build of the same source, e.g. the ASan/UBSan one
+# (`make -C oracle asan`, tools/oracle_asan.sh)
+_LIB_PATH = os.environ.get("OC_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboc_oracle.so")
 _lib = None
 
 
 def build(force=False):
+    if os.environ.get("OC_ORACLE_LIB"):
+        return _LIB_PATH
     src = os.path.join(_HERE, "oc_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "oc_level.h")
     if (not force and os.path.exists(_LIB_PATH)

@@ -193,3 +193,57 @@ def test_metrics_allgather_two_ranks_gloo(tmp_path):
         env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "rank_0.ok").exists() and (tmp_path / "rank_1.ok").exists()
+
+
+def _create(L, blob):
+    h = ctypes.c_void_p()
+    blob = np.ascontiguousarray(blob, dtype=np.int32)
+    rc = L.oc_level_create(blob.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(blob.size), ctypes.byref(h))
+    return rc, L.oc_last_error().decode()
+
+
+def test_level_validation_happens_before_any_device_work():
+    """oc_level_create rejects unsupported levels with OC_E_BADARG (-1) on a machine without
+    a GPU; a valid level only fails later, at the device step, with OC_E_NODEVICE (-2)."""
+    import torch
+    from gym_comm_amd import _lib, compiler as C, levels as L
+    lib = _lib.load()
+    ok = C.compile_level("open-divider_tomato", 2, 100)
+    rc, msg = _create(lib, ok.blob)
+    assert rc == (0 if torch.cuda.is_available() else -2), msg
+    # two tomatoes: the HIP path keys an object by its type SET
+    spec = L.load_level("open-divider_tomato")
+    spec.map_items.append((L.TOMATO, 6, 2))
+    two = C.compile_level(spec, 2, 100)
+    assert not two.hip_supported
+    rc, msg = _create(lib, two.blob)
+    assert rc == -1 and "twice" in msg
+    bad = ok.blob.copy(); bad[4] = 1                       # one agent
+    assert _create(lib, bad)[0] == -1
+    bad = ok.blob.copy(); bad[23] += 1                     # wrong total length
+    assert _create(lib, bad)[0] == -1
+    bad = ok.blob.copy(); bad[1] = 1                       # old blob version
+    assert _create(lib, bad)[0] == -1
+
+
+def test_specialised_library_refuses_other_levels():
+    import torch
+    from gym_comm_amd import _lib, compiler as C, specialize
+    a = C.compile_level("open-divider_tomato", 2, 100)
+    b = C.compile_level("full-divider_salad", 2, 100)
+    path = specialize.ensure(a.blob)
+    if path is None:
+        pytest.skip("hipcc unavailable and no cached specialisation")
+    lib = _lib.load(path)
+    assert lib.oc_is_specialized() == 1 and _lib.load().oc_is_specialized() == 0
+    rc, msg = _create(lib, b.blob)
+    assert rc == -1 and "different level" in msg
+    rc, msg = _create(lib, a.blob)
+    assert rc == (0 if torch.cuda.is_available() else -2), msg
+    # T and the ALLERGIC flags are run-time arguments: same specialisation
+    c = C.compile_level("open-divider_tomato", 2, 500, ego_allergic=True)
+    assert specialize.spec_key(c.blob) == specialize.spec_key(a.blob)
+    d = C.compile_level("open-divider_tomato", 2, 100, subtask_order=[2, 0, 1])
+    assert specialize.spec_key(d.blob) != specialize.spec_key(a.blob)
+    text = specialize.spec_header_text(a.blob)
+    assert text.startswith("// generated") and "constexpr LevelHdr OC_SPEC_HDR" in text
