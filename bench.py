@@ -231,7 +231,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s",
+            "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
