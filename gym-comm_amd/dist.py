@@ -6,7 +6,7 @@ code runs over gloo on CPU tensors in the tests).
 The reference has no distributed code at all; this is new.
 """
 import os
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 

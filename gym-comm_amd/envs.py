@@ -27,7 +27,6 @@ import torch
 
 from . import levels as L
 from .batched import BatchedOvercooked, obs_layout
-from .compiler import KIND_NAME
 
 NAV_ACTIONS = [(0, 1), (0, -1), (-1, 0), (1, 0)]        # utils/world.py:16
 _CODE_OF = {(0, 1): 0, (0, -1): 1, (-1, 0): 2, (1, 0): 3, (0, 0): 4}

@@ -26,7 +26,7 @@ policies that live on the GPU.
 import numpy as np
 import torch
 
-from .batched import OBS_KEYS, BatchedOvercooked
+from .batched import BatchedOvercooked
 from .envs import _arg, make_spaces
 
 try:                                                    # pragma: no cover - SB3 absent in CI image

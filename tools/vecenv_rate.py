@@ -7,7 +7,6 @@ import time
 from types import SimpleNamespace
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 
 from gym_comm_amd.vec_env import OvercookedVecEnv
