@@ -1353,7 +1353,7 @@ int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_
 int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, const oc_obs_cfg *cfg,
            int32_t *obs, double *timestep, int64_t n, void *stream) {
   if (lv && cfg && n == 0) return OC_OK;
-  if (!lv || !state || !comm || !cfg || !obs || !timestep || n < 0 || cfg->num_comm < 0 || cfg->num_comm > 64)
+  if (!lv || !state || !comm || !cfg || !obs || !timestep || n < 0 || cfg->num_comm < 0 || cfg->num_comm > 128)
     return fail(OC_E_BADARG, "oc_obs: bad argument");
   if (!fits_buffer(n, 2 * (22 + lv->hdr.S + 2 * cfg->num_comm), 4))
     return fail(OC_E_BADARG, "oc_obs: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
@@ -1383,7 +1383,7 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
                   int64_t n, void *stream) {
   if (lv && cfg && n == 0) return OC_OK;
   if (!lv || !state || !comm || !actions || !cfg || !obs || !timestep || !reward || !done || n < 0 ||
-      cfg->obs.num_comm < 0 || cfg->obs.num_comm > 64)
+      cfg->obs.num_comm < 0 || cfg->obs.num_comm > 128)
     return fail(OC_E_BADARG, "oc_multi_step: bad argument");
   if (lv->hdr.A != 2)
     return fail(OC_E_BADARG, "oc_multi_step: the gym_comm wrapper drives exactly 2 agents");

@@ -737,7 +737,7 @@ OC_EXPORT void oc_oracle_batch_multi_step(void **envs, int64_t n0, int64_t n1, i
     reward[i] = (double)r - sh[0] - sh[1];                             /* :282 */
     done[i] = d;
     if (auto_reset && d) env_reset(e);
-    int32_t tmp[64];
+    int32_t tmp[22 + OC_MAX_SUBTASKS + 2 * 128]; /* C <= 128 */
     int32_t cm[2] = {comm[i], comm[n_stride + i]};
     for (int v = 0; v < 2; v++) {
       double ts;

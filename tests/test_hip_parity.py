@@ -309,3 +309,36 @@ def test_fow_image_obs_matches_reference_golden(path, spec):
             assert (m[..., lane] == z["maps"][k]).all(), (k, lane)
         assert (hold.cpu().numpy() == z["holding"][k][:, None]).all(), k
         assert (env.completed_subtasks().cpu().numpy() == z["completed"][k][:, None]).all(), k
+
+
+def test_hundred_comm_channels_like_the_reference_configs(oracle_lib):
+    """spread/env_args100on.json: random-salad-superwide, num_communication = 100, T = 900."""
+    from gym_comm_amd import compiler
+    level, C, T = "random-salad-superwide", 100, 900
+    lv = compiler.compile_level(level, 2, T)
+    n, steps = 200, 120
+    rng = np.random.default_rng(3)
+    place = np.zeros((lv.num_items, n), np.int32)
+    for i in range(n):
+        pick = rng.choice(len(lv.counters), size=len(lv.scatter_items), replace=False)
+        for k, item in enumerate(lv.scatter_items):
+            x, y = lv.counters[pick[k]]
+            place[item, i] = x | (y << 4)
+    mv = rng.integers(0, 4, (steps, 2, n)).astype(np.int32)
+    cm = rng.integers(0, C, (steps, 2, n)).astype(np.int32)
+    acts = np.stack([mv[:, 0], cm[:, 0], mv[:, 1], cm[:, 1]], axis=1).astype(np.int32)
+    ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
+    ora.set_placement(place)
+    ora.reset()
+    comm = np.zeros((2, n), np.int32)
+    env = _env(lv, n, num_communication=C, fow_radius=2, auto_reset=True, placement_mode="host")
+    env.set_placement(torch.from_numpy(place).cuda())
+    env.reset()
+    assert env.F == 22 + 9 + 200
+    a_d = torch.from_numpy(acts).cuda()
+    for k in range(steps):
+        o, t, r, d = env.multi_step(a_d[k])
+        oo, to, ro, do = ora.multi_step(acts[k], comm, 2, 0, C, auto_reset=True)
+        assert np.array_equal(o.cpu().numpy(), oo), k
+        assert np.array_equal(bits(r.cpu().numpy()), bits(ro)), k
+        assert np.array_equal(bits(t.cpu().numpy()), bits(to)), k

@@ -247,3 +247,21 @@ def test_specialised_library_refuses_other_levels():
     assert specialize.spec_key(d.blob) != specialize.spec_key(a.blob)
     text = specialize.spec_header_text(a.blob)
     assert text.startswith("// generated") and "constexpr LevelHdr OC_SPEC_HDR" in text
+
+
+def test_env_args_json_loader(tmp_path):
+    from gym_comm_amd.arglist import load_env_args
+    cfg = {"level": "random-salad-superwide", "num_agents": 2, "max_num_timesteps": 900,
+           "env_config": {}, "hyperparams": {"n_steps": 5000}, "communication_on": True,
+           "num_communication": 100, "ego_led": False, "fow_radius": 2, "wandb": True}
+    p = tmp_path / "env_args.json"
+    p.write_text(__import__("json").dumps(cfg))
+    a = load_env_args(str(p))
+    assert (a.level, a.num_agents, a.max_num_timesteps, a.num_communication) == (
+        "random-salad-superwide", 2, 900, 100)
+    assert a.ego_config == {} and a.partner_config == {} and a.max_num_subtasks == 14
+    assert a.communication_on is True and a.hyperparams == {"n_steps": 5000}
+    b = load_env_args(dict(cfg, ego_config={"ALLERGIC": True, "BLIND": False, "CAN_MOVE": False}))
+    assert b.ego_config["ALLERGIC"] is True and b.ego_config["CAN_MOVE"] is False
+    with pytest.raises(KeyError):
+        load_env_args({"num_agents": 2})
