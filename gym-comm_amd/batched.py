@@ -201,7 +201,7 @@ class BatchedOvercooked:
         """completed_subtasks of every env as int32 [S][n] (from the packed state)."""
         word = self.state[self.A + self.M]
         bits = torch.arange(self.S, device=self.device, dtype=torch.int32).view(-1, 1)
-        return (word.view(1, -1) >> (16 + bits)) & 1
+        return (word.view(1, -1) >> bits) & 1
 
     def obs_dict(self, viewer: int):
         """The 11 observation keys of get_observation2 as tensor views: key -> [k][n]

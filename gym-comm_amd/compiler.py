@@ -28,7 +28,7 @@ VERSION = 2
 HEADER_WORDS = 32
 MAX_AGENTS = 4
 MAX_ITEMS = 8
-MAX_SUBTASKS = 16
+MAX_SUBTASKS = 32
 MAX_CELLS = 128
 
 KIND_CHOP, KIND_MERGE, KIND_DELIVER = 0, 1, 2

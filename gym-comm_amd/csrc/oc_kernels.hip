@@ -37,7 +37,7 @@
 
 namespace {
 
-constexpr int MAX_GOALS = 8;    // distinct goal type-sets
+constexpr int MAX_GOALS = 16;   // distinct goal type-sets (all 15 non-empty subsets of 4 types fit)
 constexpr int MAX_DELS = 4;     // Deliver subtasks
 constexpr int MAX_PAIRLK = 12;  // item-pair distance lookups of the shaping pair term
 constexpr int PLATE_BIT = 1 << OC_PLATE;
@@ -156,23 +156,25 @@ __device__ __forceinline__ void unpack(Env<A, M> &e, const int32_t *w) {
     e.isq[i] = (v >> 16) & 255;
     e.its[i] = (v >> 24) & 15;
   }
-  e.t = w[A + M] & 0xFFFF;
-  e.completed = (w[A + M] >> 16) & 0xFFFF;
-  e.goalcnt = w[A + M + 1] & 0xFFFF;
-  e.mctr = (w[A + M + 1] >> 16) & 255;
-  e.err = (w[A + M + 1] >> 24) & 255;
+  e.t = (w[0] >> 16) & 0xFFFF;
+  e.mctr = (w[1] >> 16) & 255;
+  e.err = (w[1] >> 24) & 255;
+  e.completed = w[A + M];
+  e.goalcnt = w[A + M + 1];
 }
 
 template <int A, int M>
 __device__ __forceinline__ void pack(const Env<A, M> &e, int32_t *w) {
 #pragma unroll
   for (int a = 0; a < A; a++) w[a] = e.ap[a] | ((e.ah[a] + 1) << 8);
+  w[0] |= e.t << 16;
+  w[1] |= (e.mctr << 16) | (e.err << 24);
 #pragma unroll
   for (int i = 0; i < M; i++)
     w[A + i] = e.ip[i] | (e.ist[i] << 8) | (e.ig[i] << 9) | ((e.iho[i] + 1) << 12) | (e.isq[i] << 16) |
                (e.its[i] << 24);
-  w[A + M] = e.t | (e.completed << 16);
-  w[A + M + 1] = e.goalcnt | (e.mctr << 16) | (e.err << 24);
+  w[A + M] = e.completed;
+  w[A + M + 1] = e.goalcnt;
 }
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
@@ -1064,11 +1066,14 @@ bool tables_in_lds(int64_t) {
 #define OC_FOR_AM(X)                          \
   if (A_ == 2 && M_ == 3) { X(2, 3); }        \
   if (A_ == 2 && M_ == 4) { X(2, 4); }        \
+  if (A_ == 2 && M_ == 5) { X(2, 5); }        \
   if (A_ == 3 && M_ == 3) { X(3, 3); }        \
   if (A_ == 3 && M_ == 4) { X(3, 4); }        \
+  if (A_ == 3 && M_ == 5) { X(3, 5); }        \
   if (A_ == 4 && M_ == 3) { X(4, 3); }        \
   if (A_ == 4 && M_ == 4) { X(4, 4); }        \
-  return fail(OC_E_BADARG, "unsupported (num_agents, num_items): need A in 2..4, M in 3..4");
+  if (A_ == 4 && M_ == 5) { X(4, 5); }        \
+  return fail(OC_E_BADARG, "unsupported (num_agents, num_items): need A in 2..4, M in 3..5");
 #endif
 
 int tset_of_sig(int sig) {
@@ -1403,6 +1408,8 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
                                     : launch(k_multi_step<3, false>, a, n, stream, 0);
   if (lv->hdr.M == 4) return in_lds ? launch(k_multi_step<4, true>, a, n, stream, lds)
                                     : launch(k_multi_step<4, false>, a, n, stream, 0);
+  if (lv->hdr.M == 5) return in_lds ? launch(k_multi_step<5, true>, a, n, stream, lds)
+                                    : launch(k_multi_step<5, false>, a, n, stream, 0);
   return fail(OC_E_BADARG, "oc_multi_step: unsupported number of items");
 #endif
 }

@@ -23,14 +23,14 @@ def unpack_state(words, A, M, S):
     key = np.where(is_rep, seq, 1 << 20)
     idx = np.argsort(key, axis=1, kind="stable")
     order = np.where(np.take_along_axis(is_rep, idx, axis=1), idx, -1)
-    m0, m1 = w[A + M], w[A + M + 1]
+    m0, m1 = w[A + M] & 0xFFFFFFFF, w[A + M + 1] & 0xFFFFFFFF
     bits = np.arange(S)
     return {
         "items": items.astype(np.int32), "order": order.astype(np.int32),
-        "agents": agents.astype(np.int32), "t": (m0 & 0xFFFF).astype(np.int32),
-        "completed": (((m0 >> 16)[:, None] >> bits) & 1).astype(np.int32),
+        "agents": agents.astype(np.int32), "t": ((w[0] >> 16) & 0xFFFF).astype(np.int32),
+        "completed": ((m0[:, None] >> bits) & 1).astype(np.int32),
         "goal_count": ((m1[:, None] >> bits) & 1).astype(np.int32),
-        "merge_counter": ((m1 >> 16) & 255).astype(np.int32),
-        "error": ((m1 >> 24) & 255).astype(np.int32),
+        "merge_counter": ((w[1] >> 16) & 255).astype(np.int32),
+        "error": ((w[1] >> 24) & 255).astype(np.int32),
         "nobj": is_rep.sum(axis=1).astype(np.int32),
     }

@@ -42,8 +42,9 @@ enum {
 typedef struct oc_level oc_level_t; /* opaque; device-resident static tables */
 
 /* ---- state tensor ----------------------------------------------------------
- * int32 [oc_state_words()][n].  Rows (A agents, M items):
+ * int32 [oc_state_words()][n].  Rows (A >= 2 agents, M items, S <= 32 subtasks):
  *   row a           agent a : x | y<<4 | (held_group+1)<<8           (0 = empty hands)
+ *                             row 0 also carries t<<16, row 1 merge_counter<<16 | error_flags<<24
  *   row A+i         item i  : x | y<<4 | chopped<<8 | group<<9 | (holder+1)<<12 | seq<<16 | tset<<24
  *                             group  = smallest item id in the same Object
  *                             holder = agent holding that Object
@@ -51,8 +52,8 @@ typedef struct oc_level oc_level_t; /* opaque; device-resident static tables */
  *                                      order (initial items 0..M-1, the k-th merge of
  *                                      the episode gets M+k)
  *                             tset   = set of content types of the Object (bit t = type t)
- *   row A+M         t | completed_subtasks_bitmask<<16
- *   row A+M+1       goal_objects_count bits | merge_counter<<16 | error_flags<<24
+ *   row A+M         completed_subtasks bitmask (bit s = subtask s)
+ *   row A+M+1       goal_objects_count bits (bit s = the goal object of subtask s exists)
  * Replaces the World / SimAgent object graph (gym_cooking/utils/world.py:14-320,
  * utils/agent.py:258-314, utils/core.py:149-237). */
 

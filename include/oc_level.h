@@ -58,7 +58,7 @@ enum { OC_ACT_DOWN = 0, OC_ACT_UP = 1, OC_ACT_LEFT = 2, OC_ACT_RIGHT = 3, OC_ACT
 
 #define OC_MAX_AGENTS 4
 #define OC_MAX_ITEMS 8
-#define OC_MAX_SUBTASKS 16
+#define OC_MAX_SUBTASKS 32
 #define OC_MAX_CELLS 128
 #define OC_MAX_DELIV 8
 #define OC_MAX_PAIR 4

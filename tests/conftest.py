@@ -30,10 +30,13 @@ def load_golden(path):
 def compile_for(st, **kw):
     """Compile the level of a fixture with the subtask order the fixture was recorded
     with (the reference's order depends on PYTHONHASHSEED, see compiler.py)."""
-    from gym_comm_amd import compiler
+    from gym_comm_amd import compiler, levels
     e, p = st.get("ego_config", {}), st.get("partner_config", {})
+    level = st["level"]
+    if "level_text" in st:        # a level that is not built in (tests/golden custom maps)
+        level = levels.parse_level_text(st["level"], st["level_text"])
     return compiler.compile_level(
-        st["level"], st["num_agents"], st["max_num_timesteps"],
+        level, st["num_agents"], st["max_num_timesteps"],
         ego_allergic=bool(e.get("ALLERGIC")), partner_allergic=bool(p.get("ALLERGIC")),
         subtask_order=st["subtasks"], **kw)
 

@@ -377,6 +377,44 @@ def run_fow(level, T, steps, seed, radius):
     return out
 
 
+CUSTOM_LEVELS = {
+    # our own maps (not reference files): they pin what no shipped level exercises --
+    # OnionSalad / the Onion channel (29 subtasks, 5 items), two recipes that share
+    # subtasks, and two Delivery tiles (only the first one pays, shaping takes the nearer)
+    "custom-onion_salad": "-o---t-\n/     l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nOnionSalad\n\n2 1\n4 1\n4 4\n2 4",
+    "custom-two_recipes": "-----t-\n/     l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSalad\nSimpleTomato\n\n2 1\n4 1\n4 4\n2 4",
+    "custom-two_deliveries": "--*-t-\n/    l\n*    p\n-    p\n------\n\nSimpleTomato\n\n1 1\n3 2\n4 3",
+}
+
+
+def main_custom(summary):
+    H.use_custom_levels(CUSTOM_LEVELS)
+    jobs = [("custom-onion_salad", 2, 200, [("purpose", (6000, 70))]),
+            ("custom-onion_salad", 3, 150, [("purpose", (3000, 71))]),
+            ("custom-two_recipes", 2, 150, [("purpose", (4000, 72))]),
+            ("custom-two_deliveries", 2, 80, [("rand5", (500, 73)), ("purpose", (3000, 74))]),
+            ("custom-two_deliveries", 3, 80, [("purpose", (2000, 75))])]
+    for level, A, T, tapes in jobs:
+        out, sr, nd = run_base(level, A, T, tapes)
+        st = json.loads(str(out["static_json"]))
+        st["level_text"] = CUSTOM_LEVELS[level]
+        out["static_json"] = np.array(json.dumps(st))
+        fn = "cbase_%s_a%d.npz" % (level, A)
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["t"])), "sum_reward": sr, "episodes": nd}
+        print(fn, summary[fn], "S=%d" % len(st["subtasks"]), flush=True)
+    for name, level, T, steps, seed, kw in [("conion_r2", "custom-onion_salad", 200, 4000, 130, {"num_communication": 3}),
+                                            ("ctwodeliv_r1", "custom-two_deliveries", 80, 2000, 131, {"fow_radius": 1})]:
+        out, nd = run_wrapper(name, level, T, steps, seed, **kw)
+        st = json.loads(str(out["static_json"]))
+        st["level_text"] = CUSTOM_LEVELS[level]
+        out["static_json"] = np.array(json.dumps(st))
+        fn = "cwrap_%s.npz" % name
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["done"])), "episodes": nd}
+        print(fn, summary[fn], flush=True)
+
+
 def main_random(summary):
     """random-* levels: items scattered on random Counters at every
     reset with Python's global `random` (seeded here so the run is repeatable)."""
@@ -418,6 +456,13 @@ def main():
             out = run_fow(level, 100, 1500, seed, radius)
             np.savez_compressed(os.path.join(HERE, "fow_%s.npz" % name), **out)
             print("fow_%s.npz" % name, out["maps"].shape, int(out["completed"].sum()))
+        return
+    if "--custom-only" in sys.argv:
+        with open(os.path.join(HERE, "SUMMARY.json")) as f:
+            summary = json.load(f)
+        main_custom(summary)
+        with open(os.path.join(HERE, "SUMMARY.json"), "w") as f:
+            json.dump(summary, f, indent=1, sort_keys=True)
         return
     if "--random-only" in sys.argv:
         with open(os.path.join(HERE, "SUMMARY.json")) as f:
@@ -500,6 +545,7 @@ def main():
         print(fn, summary[fn], flush=True)
 
     main_random(summary)
+    main_custom(summary)          # last: it changes the working directory
     with open(os.path.join(HERE, "SUMMARY.json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
 

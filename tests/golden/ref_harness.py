@@ -84,6 +84,21 @@ def setup():
     _ready = True
 
 
+def use_custom_levels(levels):
+    """Make extra level files visible to the reference without touching its tree: the
+    reference opens 'gym_cooking/utils/levels/<name>.txt' relative to the CWD
+    (overcooked_environment.py:103), so chdir into a temp dir that has that path."""
+    setup()
+    root = tempfile.mkdtemp(prefix="oc_custom_levels_")
+    d = os.path.join(root, "gym_cooking", "utils", "levels")
+    os.makedirs(d)
+    for name, text in levels.items():
+        with open(os.path.join(d, name + ".txt"), "w") as f:
+            f.write(text)
+    os.chdir(root)
+    return root
+
+
 @contextlib.contextmanager
 def quiet():
     with contextlib.redirect_stdout(io.StringIO()):

@@ -15,7 +15,8 @@ SPEC_GOLDEN = ["base_open-divider_tomato_a2.npz", "base_full-divider_salad_a2.np
                "base_partial-divider_tl_a3.npz", "base_full-divider_tl_a4.npz",
                "wrap_tomato_r2.npz", "wrap_salad_open_c5.npz", "wrap_tl_full_blind_allergic.npz",
                "rbase_random-open-divider_salad_small_a2.npz", "rwrap_rsuperwide_c5.npz",
-               "fow_tomato_r2.npz", "fow_salad_r3.npz"]
+               "fow_tomato_r2.npz", "fow_salad_r3.npz",
+               "cbase_custom-onion_salad_a3.npz", "cwrap_conion_r2.npz", "cbase_custom-two_deliveries_a2.npz"]
 
 
 def all_spec_levels():

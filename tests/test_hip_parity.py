@@ -14,8 +14,9 @@ from spec_levels import SEEDED_CASES, SPEC_GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-BASE = golden_files("base_") + golden_files("rbase_")      # rbase_/rwrap_: random-* levels
-WRAP = golden_files("wrap_") + golden_files("rwrap_")
+# rbase_/rwrap_: random-* levels; cbase_/cwrap_: our own maps run through the reference
+BASE = golden_files("base_") + golden_files("rbase_") + golden_files("cbase_")
+WRAP = golden_files("wrap_") + golden_files("rwrap_") + golden_files("cwrap_")
 
 
 def _placement_tensor(lv, cells, n):

@@ -11,7 +11,8 @@ import pytest
 
 from conftest import ROOT, compile_for, golden_files, load_golden
 
-ALL = golden_files("base_") + golden_files("wrap_") + golden_files("rbase_") + golden_files("rwrap_")
+ALL = (golden_files("base_") + golden_files("wrap_") + golden_files("rbase_") + golden_files("rwrap_")
+       + golden_files("cbase_") + golden_files("cwrap_"))
 
 
 @pytest.mark.parametrize("path", ALL, ids=[os.path.basename(p) for p in ALL])
@@ -19,7 +20,8 @@ def test_level_compiler_matches_reference_static_tables(path):
     from gym_comm_amd import compiler as C, levels as L
     z, st = load_golden(path)
     place = [(x, y) for _, x, y in st["items"]] if st["level"].startswith("random-") else None
-    lv = C.compile_level(st["level"], st["num_agents"], st["max_num_timesteps"], placements=place)
+    level = L.parse_level_text(st["level"], st["level_text"]) if "level_text" in st else st["level"]
+    lv = C.compile_level(level, st["num_agents"], st["max_num_timesteps"], placements=place)
     assert (lv.width, lv.height) == (st["width"], st["height"])
     assert (lv.cells == np.array(st["cells"])).all()
     assert (lv.dist == np.array(st["dist"])).all()          # World.get_path_distance_between, all pairs
@@ -29,7 +31,13 @@ def test_level_compiler_matches_reference_static_tables(path):
     mine = sorted((C.KIND_NAME[s.kind], s.goal_types) for s in lv.subtasks)
     ref = sorted((k, tuple(sorted(tid[n] for a in args for n in a.split("-")))) for k, args in st["subtasks"])
     assert mine == ref
-    assert sorted(s.name for s in lv.subtasks) == sorted("%s(%s)" % (k, ", ".join(a)) for k, a in st["subtasks"])
+    # names agree up to the order of a Merge's two arguments: where two Merge actions have the
+    # same effect the reference keeps whichever its set iteration visited last (hash-seed
+    # dependent, stripsworld.py:40-43), we keep a fixed one
+    def norm(kind, args):
+        return "%s(%s)" % (kind, ", ".join(sorted(args) if kind == "Merge" else args))
+    assert sorted(norm(C.KIND_NAME[s.kind], list(s.args)) for s in lv.subtasks) == \
+        sorted(norm(k, a) for k, a in st["subtasks"])
     lv2 = compile_for(st)                                    # explicit (recorded) order
     assert [[C.KIND_NAME[s.kind], list(s.args)] for s in lv2.subtasks] == st["subtasks"]
     assert [L.TYPE_NAME[t] for t in lv.pair_types[1:]] == st["recipe0_names"]
@@ -132,8 +140,10 @@ def test_unpack_state_roundtrip():
             w[A + i, e] = (i + 1) | (i << 4) | (i << 9) | (i << 16)
     for i in (0, 2):                                      # env 1: items 0+2 merged, held by agent 1
         w[A + i, 1] = 5 | (5 << 4) | ((1 << 8) if i == 0 else 0) | (0 << 9) | (2 << 12) | (4 << 16)
-    w[A + M, 1] = 17 | (0b101 << 16)
-    w[A + M + 1, 1] = 0b010 | (1 << 16)
+    w[0, 1] |= 17 << 16
+    w[1, 1] |= 1 << 16
+    w[A + M, 1] = 0b101
+    w[A + M + 1, 1] = 0b010
     u = unpack_state(w, A, M, S)
     assert u["order"].tolist() == [[0, 1, 2, 3], [1, 3, 0, -1]]
     assert u["nobj"].tolist() == [4, 3]

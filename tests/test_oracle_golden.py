@@ -8,8 +8,10 @@ import pytest
 
 from conftest import compile_for, golden_files, load_golden
 
-BASE = golden_files("base_") + golden_files("rbase_")     # rbase_/rwrap_: random-* levels
-WRAP = golden_files("wrap_") + golden_files("rwrap_")
+# rbase_/rwrap_: random-* levels; cbase_/cwrap_: our own maps (OnionSalad, shared subtasks,
+# two Delivery tiles) run through the reference
+BASE = golden_files("base_") + golden_files("rbase_") + golden_files("cbase_")
+WRAP = golden_files("wrap_") + golden_files("rwrap_") + golden_files("cwrap_")
 
 
 def _pack(cells):
