@@ -825,3 +825,48 @@ OC_EXPORT void oc_oracle_obs_image(const void *h, int viewer, int radius, int8_t
   holding[0] = e->ahold[0] >= 0;
   holding[1] = e->ahold[1] >= 0;
 }
+
+/* Replay a whole recorded tape in one call (the golden-vector tests: no Python in the loop).
+ * reset_before[k] != 0: reset before step k, first installing placements row pl_index[k]
+ * ([rows][M] packed cells) when placements != NULL. */
+OC_EXPORT void oc_oracle_replay_base(void *h, int64_t K, const int32_t *actions, const int32_t *reset_before,
+                                     const int32_t *pl_index, const int32_t *placements, int32_t *items,
+                                     int32_t *order, int32_t *agents, int32_t *misc, int32_t *completed,
+                                     int32_t *goalcnt, int32_t *reward, int32_t *done, double *shaping,
+                                     int32_t *err) {
+  Env *e = (Env *)h;
+  for (int64_t k = 0; k < K; k++) {
+    if (reset_before[k]) {
+      if (placements) oc_oracle_set_placement(e, placements + (int64_t)pl_index[k] * e->M);
+      env_reset(e);
+    }
+    oc_oracle_step(e, actions + k * e->A, &reward[k], &done[k], shaping + 2 * k);
+    oc_oracle_snapshot(e, items + k * e->M * 5, order + k * e->M, agents + k * e->A * 3, misc + k * 2,
+                       completed + k * e->S, goalcnt + k * e->S);
+    err[k] = e->err;
+  }
+}
+
+/* Same for wrapper tapes: actions [K][4] = ego move, ego comm, alt move, alt comm; obs out
+ * [K][2][F]; ts [K][2]; comm[2] is the persistent per_agent_communications state. */
+OC_EXPORT void oc_oracle_replay_wrapper(void *h, int64_t K, const int32_t *actions, const int32_t *reset_before,
+                                        const int32_t *pl_index, const int32_t *placements, int32_t *comm,
+                                        int radius, int blind_mask, int C, int communication_on, int ego_led,
+                                        int ego_agent_idx, int can_move_mask, int32_t *obs, double *ts,
+                                        double *reward, int32_t *done) {
+  Env *e = (Env *)h;
+  void *envs[1] = {h};
+  const int F = 22 + e->S + 2 * C;
+  for (int64_t k = 0; k < K; k++) {
+    if (reset_before[k]) {
+      if (placements) oc_oracle_set_placement(e, placements + (int64_t)pl_index[k] * e->M);
+      env_reset(e);
+    }
+    int32_t o[2 * (22 + OC_MAX_SUBTASKS + 2 * 128)];
+    double t1;
+    oc_oracle_batch_multi_step(envs, 0, 1, 1, actions + 4 * k, comm, radius, blind_mask, C, communication_on,
+                               ego_led, ego_agent_idx, can_move_mask, o, &t1, &reward[k], &done[k], 0);
+    memcpy(obs + k * 2 * F, o, sizeof(int32_t) * 2 * (size_t)F);
+    ts[2 * k] = ts[2 * k + 1] = t1;
+  }
+}

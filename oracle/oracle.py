@@ -60,6 +60,9 @@ def lib():
         L.oc_oracle_batch_multi_step.argtypes = (
             [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
              _I32P, _I32P] + [ctypes.c_int] * 7 + [_I32P, _F64P, _F64P, _I32P, ctypes.c_int])
+        L.oc_oracle_replay_base.argtypes = ([ctypes.c_void_p, ctypes.c_int64] + [_I32P] * 12 + [_F64P, _I32P])
+        L.oc_oracle_replay_wrapper.argtypes = ([ctypes.c_void_p, ctypes.c_int64] + [_I32P] * 5
+                                               + [ctypes.c_int] * 7 + [_I32P, _F64P, _F64P, _I32P])
         L.oc_oracle_obs_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.POINTER(ctypes.c_int8), _I32P]
         L.oc_oracle_set_placement.argtypes = [ctypes.c_void_p, _I32P]
@@ -102,6 +105,46 @@ class OracleEnv:
 
     def reset(self):
         lib().oc_oracle_reset(self._h)
+
+    def replay_base(self, actions, reset_before, pl_index=None, placements=None):
+        """Run a recorded base-env tape in one C call; returns per-step arrays."""
+        K = len(actions)
+        A, M, S = self.A, self.M, self.S
+        act = np.ascontiguousarray(actions, dtype=np.int32).reshape(K, A)
+        rb = np.ascontiguousarray(reset_before, dtype=np.int32)
+        pi = np.ascontiguousarray(pl_index if pl_index is not None else np.zeros(K), dtype=np.int32)
+        pl = None if placements is None else np.ascontiguousarray(placements, dtype=np.int32)
+        out = {"items": np.zeros((K, M, 5), np.int32), "order": np.zeros((K, M), np.int32),
+               "agents": np.zeros((K, A, 3), np.int32), "misc": np.zeros((K, 2), np.int32),
+               "completed": np.zeros((K, S), np.int32), "goal_count": np.zeros((K, S), np.int32),
+               "reward": np.zeros(K, np.int32), "done": np.zeros(K, np.int32),
+               "shaping": np.zeros((K, 2), np.float64), "error": np.zeros(K, np.int32)}
+        lib().oc_oracle_replay_base(
+            self._h, K, _p32(act), _p32(rb), _p32(pi), _p32(pl) if pl is not None else None,
+            _p32(out["items"]), _p32(out["order"]), _p32(out["agents"]), _p32(out["misc"]),
+            _p32(out["completed"]), _p32(out["goal_count"]), _p32(out["reward"]), _p32(out["done"]),
+            _p64(out["shaping"]), _p32(out["error"]))
+        out["t"], out["nobj"] = out["misc"][:, 0], out["misc"][:, 1]
+        return out
+
+    def replay_wrapper(self, actions, reset_before, radius, blind_mask, C, communication_on, ego_led,
+                       ego_agent_idx, can_move_mask, pl_index=None, placements=None, comm=None):
+        K = len(actions)
+        F = 22 + self.S + 2 * C
+        act = np.ascontiguousarray(actions, dtype=np.int32).reshape(K, 4)
+        rb = np.ascontiguousarray(reset_before, dtype=np.int32)
+        pi = np.ascontiguousarray(pl_index if pl_index is not None else np.zeros(K), dtype=np.int32)
+        pl = None if placements is None else np.ascontiguousarray(placements, dtype=np.int32)
+        cm = np.zeros(2, np.int32) if comm is None else np.ascontiguousarray(comm, dtype=np.int32)
+        obs = np.zeros((K, 2, F), np.int32)
+        ts = np.zeros((K, 2), np.float64)
+        rew = np.zeros(K, np.float64)
+        done = np.zeros(K, np.int32)
+        lib().oc_oracle_replay_wrapper(
+            self._h, K, _p32(act), _p32(rb), _p32(pi), _p32(pl) if pl is not None else None, _p32(cm),
+            radius, blind_mask, C, int(communication_on), int(ego_led), ego_agent_idx, can_move_mask,
+            _p32(obs), _p64(ts), _p64(rew), _p32(done))
+        return obs, ts, rew, done
 
     def obs_image(self, viewer, radius):
         W, H = int(self.blob[2]), int(self.blob[3])

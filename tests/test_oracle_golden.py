@@ -27,27 +27,42 @@ def test_base_env_matches_reference(path, oracle_lib):
     z, st = load_golden(path)
     lv = compile_for(st)
     env = oracle_lib.OracleEnv(lv.blob)
-    K = len(z["t"])
-    sh_bits = z["shaping_bits"]
-    for k in range(K):
+    pl = pi = None
+    if lv.random_placement:
+        pl = np.array([_pack(row) for row in z["placements"]], np.int32)
+        pi = z["pl_index"]
+    out = env.replay_base(z["actions"], z["reset_before"], pi, pl)       # the whole tape in one C call
+    name = os.path.basename(path)
+
+    def same(a, b, what):
+        a, b = np.asarray(a), np.asarray(b)
+        if not np.array_equal(a, b):
+            k = int(np.argwhere((a != b).reshape(len(a), -1).any(axis=1))[0, 0])
+            raise AssertionError("%s: %s differs first at step %d: %s vs %s" % (name, what, k, a[k], b[k]))
+
+    same(out["reward"], z["reward"], "reward")
+    same(out["done"], z["done"], "done")
+    same(out["t"], z["t"], "t")
+    same(out["nobj"], z["nobj"], "number of objects")
+    same(out["items"], z["items"][:, :, :5], "items")
+    same(out["order"], z["order"], "world order")
+    same(out["agents"], z["agents"], "agents")
+    same(out["completed"], z["completed"], "completed_subtasks")
+    same(out["goal_count"], z["goal_count"], "goal_objects_count")
+    same(out["shaping"].view(np.uint64), z["shaping_bits"], "shaping bits")
+    assert (out["error"] == 0).all()
+    # the step-at-a-time API gives the same answers as the replay entry point
+    env2 = oracle_lib.OracleEnv(lv.blob)
+    for k in range(min(40, len(z["t"]))):
         if z["reset_before"][k]:
             if lv.random_placement:
-                env.set_placement(_pack(z["placements"][z["pl_index"][k]]))
-            env.reset()
-        r, d, sh = env.step(z["actions"][k])
-        snap = env.snapshot()
-        ctx = (os.path.basename(path), k)
-        assert r == z["reward"][k], ctx
-        assert d == z["done"][k], ctx
-        assert snap["t"] == z["t"][k], ctx
-        assert snap["nobj"] == z["nobj"][k], ctx
-        assert (snap["items"] == z["items"][k][:, :5]).all(), (ctx, snap["items"], z["items"][k])
-        assert (snap["order"] == z["order"][k]).all(), ctx
-        assert (snap["agents"] == z["agents"][k]).all(), ctx
-        assert (snap["completed"] == z["completed"][k]).all(), ctx
-        assert (snap["goal_count"] == z["goal_count"][k]).all(), ctx
-        assert (sh.view(np.uint64) == sh_bits[k]).all(), (ctx, sh, sh_bits[k].view(np.float64))
-        assert env.error == 0, ctx
+                env2.set_placement(pl[pi[k]])
+            env2.reset()
+        r, d, sh = env2.step(z["actions"][k])
+        snap = env2.snapshot()
+        assert r == z["reward"][k] and d == z["done"][k]
+        assert (snap["items"] == z["items"][k][:, :5]).all() and (snap["agents"] == z["agents"][k]).all()
+        assert (sh.view(np.uint64) == z["shaping_bits"][k]).all()
 
 
 @pytest.mark.parametrize("path", WRAP, ids=[os.path.basename(p) for p in WRAP])
@@ -57,32 +72,28 @@ def test_wrapper_matches_reference(path, oracle_lib):
     C = st["num_communication"]
     blind = (1 if st["ego_config"]["BLIND"] else 0) | (2 if st["partner_config"]["BLIND"] else 0)
     can_move = (1 if st["ego_config"]["CAN_MOVE"] else 0) | (2 if st["partner_config"]["CAN_MOVE"] else 0)
-    b = oracle_lib.OracleBatch(lv.blob, 1)
-    comm = np.zeros((2, 1), np.int32)          # per_agent_communications starts as one-hot(0)
+    env = oracle_lib.OracleEnv(lv.blob)
+    pl = pi = None
     if lv.random_placement:
-        b.set_placement(np.array(_pack(z["placements"][0]), np.int32).reshape(-1, 1))
-        b.reset()
-    # obs right after multi_reset()
-    for v in range(2):
-        o, ts = b.obs(0, v, st["fow_radius"], (blind >> v) & 1, blind & 1, C, comm[:, 0])
+        pl = np.array([_pack(row) for row in z["placements"]], np.int32)
+        pi = z["pl_index"]
+        env.set_placement(pl[0])
+        env.reset()
+    comm = np.zeros(2, np.int32)               # per_agent_communications starts as one-hot(0)
+    for v in range(2):                         # obs right after multi_reset()
+        o, ts = env.obs(v, st["fow_radius"], (blind >> v) & 1, blind & 1, C, comm)
         assert (o == z["reset_obs"][v]).all(), (v, o, z["reset_obs"][v])
         assert np.float64(ts).view(np.uint64) == z["reset_ts_bits"][v]
-    K = len(z["done"])
-    for k in range(K):
-        if z["reset_before"][k]:
-            if lv.random_placement:
-                b.set_placement(np.array(_pack(z["placements"][z["pl_index"][k]]), np.int32).reshape(-1, 1))
-            b.reset()
-        act = z["actions"][k].astype(np.int32).reshape(4, 1)
-        obs, ts, rew, done = b.multi_step(
-            act, comm, st["fow_radius"], blind, C, st["communication_on"], st["ego_led"],
-            st["ego_agent_idx"], can_move)
-        ctx = (os.path.basename(path), k)
-        assert done[0] == z["done"][k], ctx
-        assert rew.view(np.uint64)[0] == z["rew_bits"][k], (ctx, rew, z["rew_bits"][k:k + 1].view(np.float64))
-        for v in range(2):
-            assert (obs[v, :, 0] == z["obs"][k][v]).all(), (ctx, v, obs[v, :, 0], z["obs"][k][v])
-            assert ts.view(np.uint64)[0] == z["ts_bits"][k][v], ctx
+    obs, ts, rew, done = env.replay_wrapper(
+        z["actions"], z["reset_before"], st["fow_radius"], blind, C, st["communication_on"],
+        st["ego_led"], st["ego_agent_idx"], can_move, pi, pl, comm)
+    name = os.path.basename(path)
+    assert np.array_equal(done, z["done"]), name
+    bad = np.argwhere(rew.view(np.uint64) != z["rew_bits"])
+    assert len(bad) == 0, (name, "reward bits differ first at step", int(bad[0, 0]))
+    bad = np.argwhere((obs != z["obs"]).reshape(len(obs), -1).any(axis=1))
+    assert len(bad) == 0, (name, "obs differ first at step", int(bad[0, 0]))
+    assert np.array_equal(ts.view(np.uint64), z["ts_bits"]), name
 
 
 FOW = golden_files("fow_")
