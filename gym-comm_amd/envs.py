@@ -160,6 +160,38 @@ class OvercookedEnvironment:
     def __str__(self):
         return "\n".join("".join(c + " " for c in row) for row in self.rep)
 
+    # sprite-free frame for video logging (episode_recorder.py feeds pygame sprite frames of
+    # misc/game/gameimage.py to wandb; those PNG assets are not reproduced here)
+    _TILE_RGB = {0: (232, 220, 196), 1: (150, 108, 72), 2: (120, 120, 128), 3: (96, 176, 96)}
+    _TYPE_RGB = {"Tomato": (214, 40, 40), "Lettuce": (60, 170, 60), "Onion": (200, 160, 210),
+                 "Plate": (250, 250, 250)}
+    _AGENT_RGB = [(40, 90, 200), (230, 140, 30), (150, 60, 170), (40, 170, 170)]
+
+    def render_rgb(self, scale=24):
+        """H*scale x W*scale x 3 uint8 image of the current state: tiles, items (a dot per
+        content, darker when chopped) and agents.  Not a pixel copy of the reference's
+        pygame renderer."""
+        lv = self._b.level
+        img = np.zeros((lv.height * scale, lv.width * scale, 3), np.uint8)
+        for y in range(lv.height):
+            for x in range(lv.width):
+                img[y * scale:(y + 1) * scale, x * scale:(x + 1) * scale] = self._TILE_RGB[int(lv.cells[y][x])]
+        q = max(2, scale // 4)
+        for ag_i, ag in enumerate(self.sim_agents):
+            x, y = ag.location
+            img[y * scale + 2:(y + 1) * scale - 2, x * scale + 2:(x + 1) * scale - 2] = \
+                self._AGENT_RGB[ag_i % len(self._AGENT_RGB)]
+        for o in self.world.objects_in_order:
+            x, y = o.location
+            for k, c in enumerate(sorted(o.contents, key=lambda c: c.name)):
+                col = np.array(self._TYPE_RGB[c.name], np.int32)
+                if c.name != "Plate" and c.state_index:
+                    col = col * 2 // 3
+                ox = x * scale + 2 + (k % 2) * (q + 2)
+                oy = y * scale + 2 + (k // 2) * (q + 2)
+                img[oy:oy + q, ox:ox + q] = col.astype(np.uint8)
+        return img
+
     def display(self):
         self.rep = self._render()
 

@@ -44,6 +44,9 @@ def test_base_env_adapter_matches_reference_strings(idx):
     assert tot in (5, 9)
     with pytest.raises(KeyError):
         env.step({"agent-0": (0, 1)})                     # missing agent name (reference :217)
+    frame = env.render_rgb(scale=16)
+    assert frame.shape == (env.world.height * 16, env.world.width * 16, 3) and frame.dtype == np.uint8
+    assert frame.reshape(-1, 3).std(axis=0).min() > 0          # not a blank image
     env.reset()
     assert env.t == 0 and str(env) == g["reset_str"]
 
