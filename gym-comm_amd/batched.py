@@ -9,6 +9,7 @@ Mirrors, batched:
   gym_comm.envs.OvercookedMultiEnv.multi_step/multi_reset/get_observation2
                                                        (overcooked_env.py:105-297)
 """
+import contextlib
 import ctypes
 from typing import Optional
 
@@ -59,6 +60,8 @@ class BatchedOvercooked:
             raise _lib.OcError("BatchedOvercooked needs a ROCm device (got %s); there is no CPU path"
                                % self.device)
         self.n = int(num_envs)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self._dev_index)
         self.A, self.M, self.S = lv.num_agents, lv.num_items, lv.num_subtasks
         self.C = int(num_communication)
         self.auto_reset = bool(auto_reset)
@@ -115,6 +118,13 @@ class BatchedOvercooked:
             self._h = None
 
     # -- helpers ---------------------------------------------------------------
+    def _on_device(self):
+        """Kernels must be launched with this env's device current (one process per GPU is
+        the normal case and costs nothing here)."""
+        if torch.cuda.current_device() == self._dev_index:
+            return contextlib.nullcontext()
+        return torch.cuda.device(self.device)
+
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -136,9 +146,10 @@ class BatchedOvercooked:
         """Reset all envs, or those with mask[n] != 0 (int32 [n])."""
         if mask is not None:
             self._check_tensor(mask, (self.n,), torch.int32, "mask")
-        _lib.check(self._L.oc_reset(self._h, self._p(self.state), self._p(mask),
-                                    self._p(self.placement), self._p(self.rng), self.n,
-                                    self._stream()), "oc_reset", self._L)
+        with self._on_device():
+            _lib.check(self._L.oc_reset(self._h, self._p(self.state), self._p(mask),
+                                        self._p(self.placement), self._p(self.rng), self.n,
+                                        self._stream()), "oc_reset", self._L)
 
     def set_placement(self, placement: torch.Tensor):
         """placement_mode='host': the start cells (int32 [M][n], x | y<<4, world order) every
@@ -154,18 +165,20 @@ class BatchedOvercooked:
         pre-allocated tensors, overwritten by the next call."""
         self._check_tensor(actions, (self.A, self.n), torch.int32, "actions")
         ar = self.auto_reset if auto_reset is None else auto_reset
-        _lib.check(self._L.oc_step(self._h, self._p(self.state), self._p(actions),
-                                   self._p(self.reward), self._p(self.done), self._p(self.shaping),
-                                   int(ar), self._p(self.metrics), self._p(self.placement),
-                                   self._p(self.rng), self.n, self._stream()), "oc_step", self._L)
+        with self._on_device():
+            _lib.check(self._L.oc_step(self._h, self._p(self.state), self._p(actions),
+                                       self._p(self.reward), self._p(self.done), self._p(self.shaping),
+                                       int(ar), self._p(self.metrics), self._p(self.placement),
+                                       self._p(self.rng), self.n, self._stream()), "oc_step", self._L)
         return self.reward, self.done, self.shaping
 
     def observe(self):
         """Both viewers' observations of the current state.  Returns (obs int32 [2][F][n],
         timestep f64 [n])."""
-        _lib.check(self._L.oc_obs(self._h, self._p(self.state), self._p(self.comm),
-                                  ctypes.byref(self._obs_cfg), self._p(self.obs),
-                                  self._p(self.timestep), self.n, self._stream()), "oc_obs", self._L)
+        with self._on_device():
+            _lib.check(self._L.oc_obs(self._h, self._p(self.state), self._p(self.comm),
+                                      ctypes.byref(self._obs_cfg), self._p(self.obs),
+                                      self._p(self.timestep), self.n, self._stream()), "oc_obs", self._L)
         return self.obs, self.timestep
 
     def multi_step(self, actions: torch.Tensor, auto_reset: Optional[bool] = None):
@@ -173,12 +186,13 @@ class BatchedOvercooked:
         ego comm, alt move, alt comm.  Returns (obs, timestep, shaped_reward f64[n], done)."""
         self._check_tensor(actions, (4, self.n), torch.int32, "actions")
         ar = self.auto_reset if auto_reset is None else auto_reset
-        _lib.check(self._L.oc_multi_step(
-            self._h, self._p(self.state), self._p(self.comm), self._p(actions),
-            ctypes.byref(self._wrap_cfg), self._p(self.obs), self._p(self.timestep),
-            self._p(self.shaped_reward), self._p(self.done), self._p(self.reward), int(ar),
-            self._p(self.metrics), self._p(self.placement), self._p(self.rng), self.n,
-            self._stream()), "oc_multi_step", self._L)
+        with self._on_device():
+            _lib.check(self._L.oc_multi_step(
+                self._h, self._p(self.state), self._p(self.comm), self._p(actions),
+                ctypes.byref(self._wrap_cfg), self._p(self.obs), self._p(self.timestep),
+                self._p(self.shaped_reward), self._p(self.done), self._p(self.reward), int(ar),
+                self._p(self.metrics), self._p(self.placement), self._p(self.rng), self.n,
+                self._stream()), "oc_multi_step", self._L)
         return self.obs, self.timestep, self.shaped_reward, self.done
 
     def observe_image(self, radius: Optional[int] = None):
@@ -192,9 +206,10 @@ class BatchedOvercooked:
                                       device=self.device)
             self._holding = torch.zeros((2, self.n), dtype=torch.int8, device=self.device)
         r = self._obs_cfg.fow_radius if radius is None else int(radius)
-        _lib.check(self._L.oc_obs_image(self._h, self._p(self.state), r, self._p(self._image),
-                                        self._p(self._holding), self.n, self._stream()),
-                   "oc_obs_image", self._L)
+        with self._on_device():
+            _lib.check(self._L.oc_obs_image(self._h, self._p(self.state), r, self._p(self._image),
+                                            self._p(self._holding), self.n, self._stream()),
+                       "oc_obs_image", self._L)
         return self._image.view(2, 7, lv.width, lv.height, self.n), self._holding
 
     def completed_subtasks(self):
