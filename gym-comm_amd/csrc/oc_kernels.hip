@@ -379,7 +379,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
                                          const int (&act_in)[A], int &reward, int &done, int &success,
                                          double &s0, double &s1 OC_STAMP_PARAM) {
   const int W = L.W, H = L.H;
-  e.t += 1;  // :213
+  e.t = min(e.t + 1, 0xFFFF);  // :213 (16-bit field: saturates; max_num_timesteps <= 65535 is enforced)
 
   // ---- check_collisions (:578-613) on the ORIGINAL actions -------------------
   int act[A], dx[A], dy[A], np[A];
