@@ -95,6 +95,7 @@ class BatchedOvercooked:
                                       (1 if self.ego_config["CAN_MOVE"] else 0) |
                                       (2 if self.partner_config["CAN_MOVE"] else 0))
         self._layout = obs_layout(self.S, self.C)
+        self._ms_args = None
         # random-* levels: item start cells differ per env and per episode
         self.placement = None
         self.rng = None
@@ -126,7 +127,14 @@ class BatchedOvercooked:
         return torch.cuda.device(self.device)
 
     def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return ctypes.c_void_p(self._raw_stream())
+
+    def _raw_stream(self):
+        """hipStream_t of torch's current stream on this env's device, as an int."""
+        try:
+            return torch._C._cuda_getCurrentRawStream(self._dev_index)      # ~0.3 us
+        except AttributeError:                                             # older/newer torch
+            return torch.cuda.current_stream(self.device).cuda_stream
 
     @staticmethod
     def _p(t: Optional[torch.Tensor]):
@@ -185,14 +193,23 @@ class BatchedOvercooked:
         """gym_comm wrapper step in one launch.  actions: int32 [4][n] = ego move (0..3),
         ego comm, alt move, alt comm.  Returns (obs, timestep, shaped_reward f64[n], done)."""
         self._check_tensor(actions, (4, self.n), torch.int32, "actions")
-        ar = self.auto_reset if auto_reset is None else auto_reset
-        with self._on_device():
-            _lib.check(self._L.oc_multi_step(
-                self._h, self._p(self.state), self._p(self.comm), self._p(actions),
-                ctypes.byref(self._wrap_cfg), self._p(self.obs), self._p(self.timestep),
-                self._p(self.shaped_reward), self._p(self.done), self._p(self.reward), int(ar),
-                self._p(self.metrics), self._p(self.placement), self._p(self.rng), self.n,
-                self._stream()), "oc_multi_step", self._L)
+        a = self._ms_args
+        if a is None:       # every pointer but `actions` is fixed for the life of the env
+            dp = lambda t: 0 if t is None else t.data_ptr()
+            a = self._ms_args = [self._h, dp(self.state), dp(self.comm), 0, ctypes.byref(self._wrap_cfg),
+                                 dp(self.obs), dp(self.timestep), dp(self.shaped_reward), dp(self.done),
+                                 dp(self.reward), 0, dp(self.metrics), dp(self.placement), dp(self.rng),
+                                 self.n, 0]
+        a[3] = actions.data_ptr()
+        a[10] = int(self.auto_reset if auto_reset is None else auto_reset)
+        a[15] = self._raw_stream()
+        if torch.cuda.current_device() == self._dev_index:
+            rc = self._L.oc_multi_step(*a)
+        else:
+            with torch.cuda.device(self.device):
+                rc = self._L.oc_multi_step(*a)
+        if rc:
+            _lib.check(rc, "oc_multi_step", self._L)
         return self.obs, self.timestep, self.shaped_reward, self.done
 
     def observe_image(self, radius: Optional[int] = None):
