@@ -702,14 +702,14 @@ __device__ __forceinline__ uint32_t pcg32(uint32_t &state) {
 }
 
 template <int A, int M>
-__device__ __forceinline__ void place_items(const LevelHdr &L, const Tables &tb, const int32_t *placement,
-                                            uint32_t *rng, int64_t n, int64_t i, int32_t (&w)[A + M + 2]) {
+__device__ __forceinline__ void place_items_from(const LevelHdr &L, const Tables &tb, const int32_t *placement,
+                                                 bool use_rng, uint32_t &st, int64_t n, int64_t i,
+                                                 int32_t (&w)[A + M + 2]) {
   if (L.nscatter == 0) return;  // uniform (compile-time in specialised builds)
   int pos[M];
 #pragma unroll
   for (int k = 0; k < M; k++) pos[k] = w[A + k] & 255;
-  if (rng != nullptr) {
-    uint32_t st = rng[i];
+  if (use_rng) {
     unsigned long long taken = 0;
     for (int k = 0; k < (int)L.nscatter; k++) {
       int idx = 0;
@@ -728,13 +728,23 @@ __device__ __forceinline__ void place_items(const LevelHdr &L, const Tables &tb,
 #pragma unroll
       for (int m = 0; m < M; m++) pos[m] = (item == m) ? cell : pos[m];
     }
-    rng[i] = st;
   } else if (placement != nullptr) {
 #pragma unroll
     for (int k = 0; k < M; k++) pos[k] = placement[(int64_t)k * n + i] & 255;
   }
 #pragma unroll
   for (int k = 0; k < M; k++) w[A + k] = (w[A + k] & ~255) | pos[k];
+}
+
+// read-modify-write form: the env's PCG32 state lives in rng[i]
+template <int A, int M>
+__device__ __forceinline__ void place_items(const LevelHdr &L, const Tables &tb, const int32_t *placement,
+                                            uint32_t *rng, int64_t n, int64_t i, int32_t (&w)[A + M + 2]) {
+  if (L.nscatter == 0) return;
+  const bool use_rng = rng != nullptr;
+  uint32_t st = use_rng ? rng[i] : 0u;
+  place_items_from<A, M>(L, tb, placement, use_rng, st, n, i, w);
+  if (use_rng) rng[i] = st;
 }
 
 struct StepArgs {
