@@ -18,7 +18,7 @@ SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destr
 
 class ObsCfg(ctypes.Structure):
     _fields_ = [("fow_radius", ctypes.c_int32), ("blind_mask", ctypes.c_int32),
-                ("num_comm", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("num_comm", ctypes.c_int32), ("obs_int8", ctypes.c_int32)]
 
 
 class WrapCfg(ctypes.Structure):

@@ -40,7 +40,7 @@ class BatchedOvercooked:
                  communication_on=True, ego_led=False, fow_radius=2, ego_agent_idx=0,
                  device="cuda", subtask_order=None, placements=None, level_dir=None,
                  max_num_subtasks=14, auto_reset=True, track_metrics=True, specialize_level="auto",
-                 seed=0, placement_mode="rng"):
+                 seed=0, placement_mode="rng", obs_dtype=torch.int32):
         cfg = {"ALLERGIC": False, "BLIND": False, "CAN_MOVE": True}   # missing CAN_MOVE = True
         self.ego_config = dict(cfg, **(ego_config or {}))
         self.partner_config = dict(cfg, **(partner_config or {}))
@@ -82,14 +82,17 @@ class BatchedOvercooked:
         self.done = torch.zeros(n, **i32)
         self.shaping = torch.zeros((2, n), dtype=torch.float64, device=self.device)
         self.comm = torch.zeros((2, n), **i32)                 # one-hot(0) (overcooked_env.py:89-91)
-        self.obs = torch.zeros((2, self.F, n), **i32)
+        if obs_dtype not in (torch.int32, torch.int8):
+            raise ValueError("obs_dtype must be torch.int32 or torch.int8")
+        self.obs = torch.zeros((2, self.F, n), dtype=obs_dtype, device=self.device)
         self.timestep = torch.zeros(n, dtype=torch.float64, device=self.device)
         self.shaped_reward = torch.zeros(n, dtype=torch.float64, device=self.device)
         self.metrics = (torch.zeros((self._L.oc_metrics_slots(n), 8), dtype=torch.int64,
                                     device=self.device) if track_metrics else None)
         self._obs_cfg = _lib.ObsCfg(int(fow_radius),
                                     (1 if self.ego_config["BLIND"] else 0) |
-                                    (2 if self.partner_config["BLIND"] else 0), self.C, 0)
+                                    (2 if self.partner_config["BLIND"] else 0), self.C,
+                                    1 if obs_dtype == torch.int8 else 0)
         self._wrap_cfg = _lib.WrapCfg(self._obs_cfg, int(bool(communication_on)), int(bool(ego_led)),
                                       int(ego_agent_idx),
                                       (1 if self.ego_config["CAN_MOVE"] else 0) |

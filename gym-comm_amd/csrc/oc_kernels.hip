@@ -208,6 +208,9 @@ struct Rows {
   __device__ __forceinline__ void st(int row, int v) const {
     __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, voff, row * rowbytes, 0);
   }
+  __device__ __forceinline__ void st8(int row, int v) const {   // rows of 1-byte elements
+    __builtin_amdgcn_raw_buffer_store_b8((char)v, rsrc, voff, row * rowbytes, 0);
+  }
   __device__ __forceinline__ void st_f64(int row, double v) const {
     typedef int v2i __attribute__((ext_vector_type(2)));
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), rsrc, voff, row * rowbytes, 0);
@@ -545,7 +548,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
 
 // get_observation2 (gym_comm/envs/overcooked_env.py:105-159) for one viewer;
 // writes F = 22 + S + 2C rows with stride n.
-template <int A, int M>
+template <int A, int M, bool O8 = false>
 __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, int viewer, int radius,
                                         bool viewer_blind, bool ego_blind, int C, int comm0, int comm1,
                                         const Rows &out, int row0) {
@@ -575,32 +578,28 @@ __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, i
     ddx[ch] = within ? 0 : ddx[ch];                 // :135 (sic: zeroed when visible)
     ddy[ch] = within ? 0 : ddy[ch];
   }
+#define OUT(r_, v_) do { if (O8) out.st8((r_), (v_)); else out.st((r_), (v_)); } while (0)
   int row = row0;
 #pragma unroll
-  for (int ch = 0; ch < 4; ch++) out.st(row++, ddx[ch]);
+  for (int ch = 0; ch < 4; ch++) OUT(row++, ddx[ch]);
 #pragma unroll
-  for (int ch = 0; ch < 4; ch++) out.st(row++, ddy[ch]);
+  for (int ch = 0; ch < 4; ch++) OUT(row++, ddy[ch]);
 #pragma unroll
-  for (int ch = 0; ch < 4; ch++) out.st(row++, st[ch]);
+  for (int ch = 0; ch < 4; ch++) OUT(row++, st[ch]);
 #pragma unroll
-  for (int ch = 0; ch < 4; ch++) out.st(row++, hid[ch]);
-  for (int s = 0; s < L.S; s++) out.st(row++, (e.completed >> s) & 1);
-  out.st(row++, viewer_blind ? 0 : px(e.ap[0]));  // :139-143
-  out.st(row++, viewer_blind ? 0 : py(e.ap[0]));
-  out.st(row++, viewer_blind ? 0 : px(e.ap[1]));
-  out.st(row++, viewer_blind ? 0 : py(e.ap[1]));
-  out.st(row++, ego_blind ? 0 : (vh >= 0 ? 1 : 0));  // :154, gated on the EGO's BLIND flag
-  out.st(row++, 0);
-  for (int c = 0; c < C; c++) out.st(row++, comm0 == c ? 1 : 0);
-  for (int c = 0; c < C; c++) out.st(row++, comm1 == c ? 1 : 0);
+  for (int ch = 0; ch < 4; ch++) OUT(row++, hid[ch]);
+  for (int s = 0; s < L.S; s++) OUT(row++, (e.completed >> s) & 1);
+  OUT(row++, viewer_blind ? 0 : px(e.ap[0]));  // :139-143
+  OUT(row++, viewer_blind ? 0 : py(e.ap[0]));
+  OUT(row++, viewer_blind ? 0 : px(e.ap[1]));
+  OUT(row++, viewer_blind ? 0 : py(e.ap[1]));
+  OUT(row++, ego_blind ? 0 : (vh >= 0 ? 1 : 0));  // :154, gated on the EGO's BLIND flag
+  OUT(row++, 0);
+  for (int c = 0; c < C; c++) OUT(row++, comm0 == c ? 1 : 0);
+  for (int c = 0; c < C; c++) OUT(row++, comm1 == c ? 1 : 0);
+#undef OUT
 }
 
-// wave-level metric accumulation: ballot/popcount for the flags and, bit-sliced, for the
-// small integers; lane k (k < 6) then adds counter k into the wave's OWN 64-byte slot of
-// the metrics tensor (int64 [ceil(n/64)][8]) -- one 48-byte load issued at kernel start,
-// one store at the end, no atomics.  (Round-1 v1 used one device-wide counter set: its
-// 2 048 same-address atomics per launch, ~11 ns each, were 60 % of the n = 131 072
-// launch.)  Launches that share a metrics tensor are ordered by the stream.
 // Sum over the wave of a small non-negative per-lane integer (< 2^BITS): one ballot +
 // scalar popcount per bit -- no cross-lane shuffles, a handful of SALU ops.
 template <int BITS>
@@ -815,13 +814,13 @@ struct ObsArgs {
   RunCfg R;
   const int32_t *state;
   const int32_t *comm;
-  int32_t *obs;
+  void *obs;          // int32 or int8 rows (cfg.obs_int8)
   double *timestep;
   int64_t n;
   oc_obs_cfg cfg;
 };
 
-template <int A, int M>
+template <int A, int M, bool O8>
 __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
   const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -837,10 +836,10 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
   const int F = 22 + L.S + 2 * C;
   const int c0 = p.comm[i], c1 = p.comm[p.n + i];
   const bool ego_blind = p.cfg.blind_mask & 1;
-  const Rows ob(p.obs, p.n, 2 * F, i);
+  const Rows ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
 #pragma unroll
   for (int v = 0; v < 2; v++)
-    env_obs<A, M>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
+    env_obs<A, M, O8>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
   p.timestep[i] = (double)e.t / (double)p.R.T;  // overcooked_env.py:146
 }
 
@@ -941,7 +940,7 @@ struct MultiArgs {
   int32_t *state;
   int32_t *comm;
   const int32_t *actions;
-  int32_t *obs;
+  void *obs;          // int32 or int8 rows (cfg.obs.obs_int8)
   double *timestep;
   double *reward;
   int32_t *done;
@@ -955,7 +954,7 @@ struct MultiArgs {
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
-template <int M, bool LDS>
+template <int M, bool LDS, bool O8>
 __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
   constexpr int A = 2;
   const LevelHdr &L = OC_HDR(p);
@@ -1014,11 +1013,11 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
-    const Rows ob(p.obs, p.n, 2 * F, i);
+    const Rows ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
 #pragma unroll
     for (int v = 0; v < 2; v++)
-      env_obs<A, M>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
-                    v * F);
+      env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
+                        v * F);
     p.timestep[i] = (double)e.t / (double)p.R.T;
   }
   OC_STAMP(7);   // every store issued
@@ -1366,7 +1365,7 @@ int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_
 }
 
 int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, const oc_obs_cfg *cfg,
-           int32_t *obs, double *timestep, int64_t n, void *stream) {
+           void *obs, double *timestep, int64_t n, void *stream) {
   if (lv && cfg && n == 0) return OC_OK;
   if (!lv || !state || !comm || !cfg || !obs || !timestep || n < 0 || cfg->num_comm < 0 || cfg->num_comm > 128)
     return fail(OC_E_BADARG, "oc_obs: bad argument");
@@ -1374,9 +1373,15 @@ int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, cons
     return fail(OC_E_BADARG, "oc_obs: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
   ObsArgs a{lv->hdr, lv->run, state, comm, obs, timestep, n, *cfg};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
-#define OC_X(AA, MM) return launch(k_obs<AA, MM>, a, n, stream, 0)
-  OC_FOR_AM(OC_X)
+  if (cfg->obs_int8) {
+#define OC_X(AA, MM) return launch(k_obs<AA, MM, true>, a, n, stream, 0)
+    OC_FOR_AM(OC_X)
 #undef OC_X
+  } else {
+#define OC_X(AA, MM) return launch(k_obs<AA, MM, false>, a, n, stream, 0)
+    OC_FOR_AM(OC_X)
+#undef OC_X
+  }
 }
 
 int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int8_t *out, int8_t *holding,
@@ -1393,7 +1398,7 @@ int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int
 }
 
 int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
-                  const oc_wrap_cfg *cfg, int32_t *obs, double *timestep, double *reward, int32_t *done,
+                  const oc_wrap_cfg *cfg, void *obs, double *timestep, double *reward, int32_t *done,
                   int32_t *sparse, int32_t auto_reset, int64_t *metrics, const int32_t *placement, uint32_t *rng,
                   int64_t n, void *stream) {
   if (lv && cfg && n == 0) return OC_OK;
@@ -1410,18 +1415,22 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
               reward, done, sparse, metrics, placement, rng, n, auto_reset, *cfg};
   const size_t lds = (size_t)lv->n16 * 16;
   const bool in_lds = tables_in_lds(n);
+  const bool o8 = cfg->obs.obs_int8 != 0;
+#define OC_MS(MM)                                                                     \
+  do {                                                                                \
+    if (o8) return launch(k_multi_step<MM, false, true>, a, n, stream, 0);           \
+    if (in_lds) return launch(k_multi_step<MM, true, false>, a, n, stream, lds);     \
+    return launch(k_multi_step<MM, false, false>, a, n, stream, 0);                  \
+  } while (0)
 #ifdef OC_SPECIALIZED
-  if (in_lds) return launch(k_multi_step<OC_SPEC_HDR.M, true>, a, n, stream, lds);
-  return launch(k_multi_step<OC_SPEC_HDR.M, false>, a, n, stream, 0);
+  OC_MS(OC_SPEC_HDR.M);
 #else
-  if (lv->hdr.M == 3) return in_lds ? launch(k_multi_step<3, true>, a, n, stream, lds)
-                                    : launch(k_multi_step<3, false>, a, n, stream, 0);
-  if (lv->hdr.M == 4) return in_lds ? launch(k_multi_step<4, true>, a, n, stream, lds)
-                                    : launch(k_multi_step<4, false>, a, n, stream, 0);
-  if (lv->hdr.M == 5) return in_lds ? launch(k_multi_step<5, true>, a, n, stream, lds)
-                                    : launch(k_multi_step<5, false>, a, n, stream, 0);
+  if (lv->hdr.M == 3) OC_MS(3);
+  if (lv->hdr.M == 4) OC_MS(4);
+  if (lv->hdr.M == 5) OC_MS(5);
   return fail(OC_E_BADARG, "oc_multi_step: unsupported number of items");
 #endif
+#undef OC_MS
 }
 
 }  // extern "C"

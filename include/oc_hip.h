@@ -58,7 +58,7 @@ typedef struct oc_level oc_level_t; /* opaque; device-resident static tables */
  * utils/agent.py:258-314, utils/core.py:149-237). */
 
 /* ---- observation tensor ----------------------------------------------------
- * int32 [2][oc_obs_rows()][n]: viewer 0 then viewer 1; rows per viewer, in the key
+ * int32 (or int8, see oc_obs_cfg.obs_int8) [2][oc_obs_rows()][n]: viewer 0 then viewer 1; rows per viewer, in the key
  * order of OvercookedMultiEnv.get_observation2
  * (gym_comm/envs/overcooked_env.py:145-157) minus `timestep`:
  *   object_encodings_x[4] object_encodings_y[4] state_encodings[4] is_hidden[4]
@@ -71,7 +71,9 @@ typedef struct {
   int32_t fow_radius;   /* arglist.fow_radius */
   int32_t blind_mask;   /* bit0: ego_config["BLIND"], bit1: partner_config["BLIND"] */
   int32_t num_comm;     /* arglist.num_communication (C) */
-  int32_t reserved;
+  int32_t obs_int8;     /* 0: observation rows are int32; 1: int8 (every value fits: the
+                           kernel then moves 4x fewer observation bytes: 10.9 -> 8.9 us per
+                           launch at 131072 envs, 1.22x) */
 } oc_obs_cfg;
 
 typedef struct {
@@ -151,7 +153,7 @@ OC_API int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions,
  * (gym_comm/envs/overcooked_env.py:105-159).
  *   comm     int32 [2][n]  per_agent_communications as the index of the set bit, -1 = zeros */
 OC_API int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, const oc_obs_cfg *cfg,
-           int32_t *obs, double *timestep, int64_t n, void *stream);
+           void *obs, double *timestep, int64_t n, void *stream);
 
 /* OvercookedMultiEnv.get_partial_observability_FOW for both viewers
  * (gym_comm/envs/overcooked_env.py:161-202), the image-style fog-of-war observation.
@@ -169,7 +171,7 @@ OC_API int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radi
  *   reward   double[n]     shaped reward, identical for both agents
  *   sparse   int32 [n] or NULL  the unshaped integer reward */
 OC_API int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
-                  const oc_wrap_cfg *cfg, int32_t *obs, double *timestep, double *reward,
+                  const oc_wrap_cfg *cfg, void *obs, double *timestep, double *reward,
                   int32_t *done, int32_t *sparse, int32_t auto_reset, int64_t *metrics,
                   const int32_t *placement, uint32_t *rng, int64_t n, void *stream);
 

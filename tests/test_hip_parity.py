@@ -343,3 +343,48 @@ def test_hundred_comm_channels_like_the_reference_configs(oracle_lib):
         assert np.array_equal(o.cpu().numpy(), oo), k
         assert np.array_equal(bits(r.cpu().numpy()), bits(ro)), k
         assert np.array_equal(bits(t.cpu().numpy()), bits(to)), k
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "step+obs"])
+@pytest.mark.parametrize("name", ["wrap_salad_open_c5.npz", "wrap_tl_full_blind_allergic.npz",
+                                  "rwrap_rsuperwide_c5.npz", "cwrap_conion_r2.npz"])
+def test_int8_observation_rows_match_reference_golden(name, fused):
+    """oc_obs_cfg.obs_int8: the same observations as int8 rows (4x fewer bytes)."""
+    path = os.path.join(os.path.dirname(BASE[0]), name)
+    z, st = load_golden(path)
+    lv = compile_for(st)
+    n = 130
+    env = _wrap_env(st, lv, n, auto_reset=False, placement_mode="host", obs_dtype=torch.int8,
+                    specialize_level=(name in SPEC_GOLDEN))
+    assert env.obs.dtype == torch.int8
+    if lv.random_placement:
+        env.set_placement(_placement_tensor(lv, z["placements"][0], n))
+        env.reset()
+    obs, ts = env.observe()
+    assert (obs.cpu().numpy()[:, :, 0] == z["reset_obs"]).all()
+    K = min(len(z["done"]), 900)
+    acts = torch.from_numpy(np.repeat(z["actions"][:K].astype(np.int32)[:, :, None], n, axis=2)).cuda()
+    can = (1 if st["ego_config"]["CAN_MOVE"] else 0) | (2 if st["partner_config"]["CAN_MOVE"] else 0)
+    for k in range(K):
+        if z["reset_before"][k]:
+            if lv.random_placement:
+                env.set_placement(_placement_tensor(lv, z["placements"][z["pl_index"][k]], n))
+            env.reset()
+        if fused:
+            o, t, r, d = env.multi_step(acts[k])
+        else:
+            a = acts[k]
+            noop = torch.full_like(a[0], 4)
+            em = a[0] if (can & 1) else noop
+            am = a[2] if (can & 2) else noop
+            base = torch.stack([em, am] if st["ego_agent_idx"] == 0 else [am, em]).contiguous()
+            neg = torch.full_like(a[1], -1)
+            env.comm[0] = a[1] if st["communication_on"] else neg
+            env.comm[1] = a[3] if (st["communication_on"] and not st["ego_led"]) else neg
+            rr, d, sh = env.step(base)
+            r = (rr.double() - sh[0]) - sh[1]
+            o, t = env.observe()
+        oh = o.cpu().numpy()
+        for lane in (0, 64, 129):
+            assert (oh[:, :, lane] == z["obs"][k]).all(), (k, lane)
+        assert (bits(r.cpu().numpy()) == z["rew_bits"][k]).all(), k

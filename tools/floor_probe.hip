@@ -17,6 +17,10 @@ __global__ void probe(const int *in, int *out, int n, int loads, int spin) {
   if (VEC == 1) {
 #pragma unroll
     for (int r = 0; r < STORES; r++) out[r * n + i] = acc + r;            // SoA rows, 256 B per wave store
+  } else if (VEC == 0) {
+    signed char *o8 = (signed char *)out;                                  // SoA byte rows, 64 B per wave store
+#pragma unroll
+    for (int r = 0; r < STORES; r++) o8[(size_t)r * n + i] = (signed char)(acc + r);
   } else {
     int4 *o = (int4 *)out + (size_t)i * (STORES / 4);                      // AoS: 16 B per lane per store
 #pragma unroll
@@ -43,7 +47,8 @@ int run(int n, int *in, int *out, hipStream_t s, int spin) {
   CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   printf("n=%6d  12 row loads, %2d words stored per env as %s, %4d dependent VALU ops: %6.2f us per launch\n", n,
-         STORES, VEC == 1 ? "row stores (SoA)  " : "dwordx4 stores (AoS)", 2 * spin, ms * 1e3 / (20 * 256));
+         STORES, VEC == 1 ? "row stores (SoA)  " : VEC == 0 ? "BYTE row stores (SoA)" : "dwordx4 stores (AoS)", 2 * spin,
+         ms * 1e3 / (20 * 256));
   CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
   return 0;
 }
@@ -64,6 +69,9 @@ int main() {
     run<76, 1>(n, in, out, s, 0);
     run<76, 4>(n, in, out, s, 0);
     run<20, 4>(n, in, out, s, 0);
+    run<76, 0>(n, in, out, s, 0);
+    run<60, 0>(n, in, out, s, 0);
+    run<31, 1>(n, in, out, s, 0);    // 16 state/scalar dword rows + 60 obs values packed 4 per dword
     run<76, 1>(n, in, out, s, 500);
     run<0, 1>(n, in, out, s, 500);
     CK(hipFree(in)); CK(hipFree(out));
