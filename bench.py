@@ -158,11 +158,20 @@ def main():
         for k in range(min(args.warmup, 64)):            # touch everything before capture
             step_fn(acts[k % WINDOW])
         stream.synchronize()
-        if use_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                for k in range(G):
+        tails = {}                                       # remainder length -> its own graph
+
+        def capture(length):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                for k in range(length):
                     step_fn(acts[k % WINDOW])
+            return g
+
+        if use_graph:
+            graph = capture(G)
+            for cnt in (args.warmup, args.steps):        # a short --steps still runs as ONE graph launch
+                if cnt % G:
+                    tails.setdefault(cnt % G, capture(cnt % G))
 
         def run(steps):
             k = 0
@@ -170,6 +179,9 @@ def main():
                 while steps - k >= G:
                     graph.replay()
                     k += G
+                if steps - k in tails:
+                    tails[steps - k].replay()
+                    k = steps
             while k < steps:
                 step_fn(acts[k % WINDOW])
                 k += 1

@@ -193,11 +193,21 @@ __device__ __forceinline__ int manhattan(int p, int q) { return iabs(px(p) - px(
 // a scalar (soffset), so a row access costs no vector address arithmetic at all.  The
 // descriptor's record count bounds the whole tensor; the tail lanes of the last wave are
 // still masked by the caller because rows are contiguous.
-struct Rows {
+//
+// AUX = cache-policy bits of the stores (bit 0 sc0, bit 1 nt, bit 4 sc1).  With sc1 (agent
+// scope) the L2 writes a line through to the fabric at once instead of holding it dirty
+// until the end-of-kernel write-back, so the write-back overlaps the rest of the launch
+// instead of trailing it.  tools/store_probe.hip (76 row stores per env): 10.4 -> 7.9 us
+// per launch at n = 131072, 4.4 -> 3.7 us at 32768; sc0 / nt change nothing.  In the
+// kernels: salad-2 x 32768 6.84 -> 5.88 us, tomato-2 x 131072 11.1 -> 10.0 us, but
+// 4.56 -> 4.66 us at n = 4096 (a lone wave per CU waits longer for its last store), so
+// the launcher picks the write-through variant (template bool WT) from 8 192 envs on.
+template <int AUX>
+struct RowsT {
   __amdgpu_buffer_rsrc_t rsrc;
   int voff;      // lane byte offset inside a row
   int rowbytes;  // n * element size
-  __device__ __forceinline__ Rows(const void *base, int64_t n, int rows, int64_t i, int elem = 4) {
+  __device__ __forceinline__ RowsT(const void *base, int64_t n, int rows, int64_t i, int elem = 4) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(n * rows * elem), 0x00020000);
     voff = (int)i * elem;
     rowbytes = (int)n * elem;
@@ -206,16 +216,18 @@ struct Rows {
     return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, row * rowbytes, 0);
   }
   __device__ __forceinline__ void st(int row, int v) const {
-    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, voff, row * rowbytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, voff, row * rowbytes, AUX);
   }
   __device__ __forceinline__ void st8(int row, int v) const {   // rows of 1-byte elements
-    __builtin_amdgcn_raw_buffer_store_b8((char)v, rsrc, voff, row * rowbytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b8((char)v, rsrc, voff, row * rowbytes, AUX);
   }
   __device__ __forceinline__ void st_f64(int row, double v) const {
     typedef int v2i __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), rsrc, voff, row * rowbytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), rsrc, voff, row * rowbytes, AUX);
   }
 };
+using Rows = RowsT<0>;          // loads and default-policy stores
+constexpr int AUX_WT = 16;      // sc1
 
 // calculate_reward_shaping for sim agents 0 and 1 (overcooked_environment.py:272-397),
 // given the agents' cells, the item cells, the completed flags and, per Deliver subtask, the
@@ -548,10 +560,10 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
 
 // get_observation2 (gym_comm/envs/overcooked_env.py:105-159) for one viewer;
 // writes F = 22 + S + 2C rows with stride n.
-template <int A, int M, bool O8 = false>
+template <int A, int M, bool O8, typename OutRows>
 __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, int viewer, int radius,
                                         bool viewer_blind, bool ego_blind, int C, int comm0, int comm1,
-                                        const Rows &out, int row0) {
+                                        const OutRows &out, int row0) {
   const int vp = viewer == 0 ? e.ap[0] : e.ap[1];
   const int vh = viewer == 0 ? e.ah[0] : e.ah[1];
   const int vx = px(vp), vy = py(vp);
@@ -763,8 +775,9 @@ struct StepArgs {
   int32_t auto_reset;
 };
 
-template <int A, int M, bool LDS>
+template <int A, int M, bool LDS, bool WT>
 __global__ void __launch_bounds__(256) k_step(const StepArgs p) {
+  using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < p.n;
@@ -774,7 +787,8 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs p) {
   bool err = false;
   if (valid) {
     constexpr int WS = A + M + 2;
-    const Rows st(p.state, p.n, WS, i), ac(p.actions, p.n, A, i);
+    const Out st(p.state, p.n, WS, i);
+    const Rows ac(p.actions, p.n, A, i);
     int32_t w[WS];
 #pragma unroll
     for (int r = 0; r < WS; r++) w[r] = st.ld(r);
@@ -791,9 +805,9 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs p) {
     env_step<A, M>(L, p.R, tb.dist, tb.quot, e, act, reward, done, success, s0, s1 OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
-    p.reward[i] = reward;
-    p.done[i] = done;
-    const Rows sh(p.shaping, p.n, 2, i, 8);
+    Out(p.reward, p.n, 1, i).st(0, reward);
+    Out(p.done, p.n, 1, i).st(0, done);
+    const Out sh(p.shaping, p.n, 2, i, 8);
     sh.st_f64(0, s0);
     sh.st_f64(1, s1);
     if (done && p.auto_reset) {
@@ -820,8 +834,9 @@ struct ObsArgs {
   oc_obs_cfg cfg;
 };
 
-template <int A, int M, bool O8>
+template <int A, int M, bool O8, bool WT>
 __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
+  using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
@@ -836,11 +851,11 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
   const int F = 22 + L.S + 2 * C;
   const int c0 = p.comm[i], c1 = p.comm[p.n + i];
   const bool ego_blind = p.cfg.blind_mask & 1;
-  const Rows ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
+  const Out ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
 #pragma unroll
   for (int v = 0; v < 2; v++)
     env_obs<A, M, O8>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
-  p.timestep[i] = (double)e.t / (double)p.R.T;  // overcooked_env.py:146
+  Out(p.timestep, p.n, 1, i, 8).st_f64(0, (double)e.t / (double)p.R.T);  // overcooked_env.py:146
 }
 
 struct ImageArgs {
@@ -897,7 +912,7 @@ __global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
 #pragma unroll
         for (int k = 0; k < 7; k++)
           __builtin_amdgcn_raw_buffer_store_b8((char)(fog ? -1 : plane[k]), rsrc, (int)i,
-                                               (int)((v * rows + (k * W + x) * H + y) * p.n), 0);
+                                               (int)((v * rows + (k * W + x) * H + y) * p.n), AUX_WT);
       }
     }
   p.holding[i] = e.ah[0] >= 0;
@@ -954,9 +969,10 @@ struct MultiArgs {
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
-template <int M, bool LDS, bool O8>
+template <int M, bool LDS, bool O8, bool WT>
 __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
   constexpr int A = 2;
+  using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < p.n;
@@ -971,7 +987,8 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
   bool err = false;
   if (valid) {
     constexpr int WS = A + M + 2;
-    const Rows st(p.state, p.n, WS, i), ac(p.actions, p.n, 4, i), cm(p.comm, p.n, 2, i);
+    const Out st(p.state, p.n, WS, i), cm(p.comm, p.n, 2, i);
+    const Rows ac(p.actions, p.n, 4, i);
     int32_t w[WS];
 #pragma unroll
     for (int r = 0; r < WS; r++) w[r] = st.ld(r);
@@ -995,10 +1012,10 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
     env_step<A, M>(L, p.R, tb.dist, tb.quot, e, act, reward, done, success, s0, s1 OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
-    p.reward[i] = ((double)reward - s0) - s1;  // :282
-    p.done[i] = done;
+    Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
+    Out(p.done, p.n, 1, i).st(0, done);
 #ifndef OC_STAMPS
-    if (p.sparse != nullptr) p.sparse[i] = reward;
+    if (p.sparse != nullptr) Out(p.sparse, p.n, 1, i).st(0, reward);
 #endif
     if (done && p.auto_reset) {
 #pragma unroll
@@ -1013,12 +1030,12 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
-    const Rows ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
+    const Out ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
 #pragma unroll
     for (int v = 0; v < 2; v++)
       env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
                         v * F);
-    p.timestep[i] = (double)e.t / (double)p.R.T;
+    Out(p.timestep, p.n, 1, i, 8).st_f64(0, (double)e.t / (double)p.R.T);
   }
   OC_STAMP(7);   // every store issued
   slot.add(p.metrics != nullptr, valid, done, success, reward, comp, err);
@@ -1037,11 +1054,12 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
 // ---------------------------------------------------------------------------
 int block_size_for(int64_t n) {
   // One wave per workgroup spreads a batch over the most CUs and measured fastest up to
-  // 131 072 envs (MI355X sweep, profiles/r01_v3_block_lds_sweep.txt); two waves per
-  // workgroup from 262 144 envs on.  OC_BLOCK overrides (tuning / tests).
+  // 262 144 envs (MI355X sweeps, profiles/r01_v3_block_lds_sweep.txt and
+  // profiles/r01_v5_wt_block_sweep.txt); two waves per workgroup from 524 288 envs on.
+  // OC_BLOCK overrides (tuning / tests).
   static const int forced = getenv("OC_BLOCK") ? atoi(getenv("OC_BLOCK")) : 0;
   if (forced == 64 || forced == 128 || forced == 256) return forced;
-  return n >= 4 * 256 * 256 ? 128 : 64;
+  return n >= 8 * 256 * 256 ? 128 : 64;
 }
 
 // rows are addressed with 32-bit byte offsets through a buffer descriptor
@@ -1057,6 +1075,12 @@ int launch(K kernel, const Args &args, int64_t n, void *stream, size_t lds_bytes
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "kernel launch");
   return OC_OK;
+}
+
+bool write_through(int64_t n) {
+  // sc1 stores (see RowsT) from 8 192 envs on (tools/wt_sweep.sh: 5.26 -> 5.06 us there); OC_WRITE_THROUGH=0/1 overrides (tuning / tests)
+  static const int forced = getenv("OC_WRITE_THROUGH") ? atoi(getenv("OC_WRITE_THROUGH")) : -1;
+  return forced >= 0 ? forced == 1 : n >= 8192;
 }
 
 bool tables_in_lds(int64_t) {
@@ -1354,11 +1378,16 @@ int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
   const size_t lds = (size_t)lv->n16 * 16;
   if (tables_in_lds(n)) {
-#define OC_X(AA, MM) return launch(k_step<AA, MM, true>, a, n, stream, lds)
+#define OC_X(AA, MM) return launch(k_step<AA, MM, true, false>, a, n, stream, lds)
     OC_FOR_AM(OC_X)
 #undef OC_X
   } else {
-#define OC_X(AA, MM) return launch(k_step<AA, MM, false>, a, n, stream, 0)
+    if (write_through(n)) {
+#define OC_X(AA, MM) return launch(k_step<AA, MM, false, true>, a, n, stream, 0)
+      OC_FOR_AM(OC_X)
+#undef OC_X
+    }
+#define OC_X(AA, MM) return launch(k_step<AA, MM, false, false>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   }
@@ -1373,12 +1402,15 @@ int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, cons
     return fail(OC_E_BADARG, "oc_obs: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
   ObsArgs a{lv->hdr, lv->run, state, comm, obs, timestep, n, *cfg};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
+  const bool wt = write_through(n);
   if (cfg->obs_int8) {
-#define OC_X(AA, MM) return launch(k_obs<AA, MM, true>, a, n, stream, 0)
+#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, true, true>, a, n, stream, 0) \
+                                : launch(k_obs<AA, MM, true, false>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   } else {
-#define OC_X(AA, MM) return launch(k_obs<AA, MM, false>, a, n, stream, 0)
+#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, false, true>, a, n, stream, 0) \
+                                : launch(k_obs<AA, MM, false, false>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   }
@@ -1416,11 +1448,14 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   const size_t lds = (size_t)lv->n16 * 16;
   const bool in_lds = tables_in_lds(n);
   const bool o8 = cfg->obs.obs_int8 != 0;
+  const bool wt = write_through(n);
 #define OC_MS(MM)                                                                     \
   do {                                                                                \
-    if (o8) return launch(k_multi_step<MM, false, true>, a, n, stream, 0);           \
-    if (in_lds) return launch(k_multi_step<MM, true, false>, a, n, stream, lds);     \
-    return launch(k_multi_step<MM, false, false>, a, n, stream, 0);                  \
+    if (in_lds && !o8) return launch(k_multi_step<MM, true, false, false>, a, n, stream, lds);      \
+    if (o8) return wt ? launch(k_multi_step<MM, false, true, true>, a, n, stream, 0)                \
+                      : launch(k_multi_step<MM, false, true, false>, a, n, stream, 0);              \
+    return wt ? launch(k_multi_step<MM, false, false, true>, a, n, stream, 0)                       \
+              : launch(k_multi_step<MM, false, false, false>, a, n, stream, 0);                     \
   } while (0)
 #ifdef OC_SPECIALIZED
   OC_MS(OC_SPEC_HDR.M);
