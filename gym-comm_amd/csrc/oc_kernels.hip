@@ -76,6 +76,7 @@ struct LevelHdr {
 struct RunCfg {
   int32_t T;          // arglist.max_num_timesteps (0 = no limit)
   uint32_t allergic;  // bit a: agent a is ALLERGIC
+  double inv_T;       // 1.0 / T, correctly rounded on the host (0 when T == 0)
 };
 
 #ifdef OC_STAMPS
@@ -132,30 +133,39 @@ int fail_hip(hipError_t e, const char *what) {
 // ---------------------------------------------------------------------------
 // per-env registers
 // ---------------------------------------------------------------------------
+// Items stay PACKED in registers exactly as they sit in the state tensor (include/oc_hip.h):
+//   x | y<<4 | chopped<<8 | group<<9 | (holder+1)<<12 | seq<<16 | tset<<24
+// Every item of one Object carries the same group / seq / tset, and on a non-Delivery cell at
+// most one unheld Object exists, so "the held Object" and "the Object on the target cell" are
+// plain ORs over the matching item words, a field test is one AND + compare on the word, and
+// an update of several fields is one bit-field insert (v_bfi_b32).
+constexpr int IW_POS = 0x000000FF, IW_CHOP = 0x00000100, IW_GRP = 0x00000E00, IW_HOLD = 0x00007000,
+              IW_SEQ = 0x00FF0000, IW_TSET = 0x0F000000;
+constexpr int IW_OBJ = IW_GRP | IW_SEQ | IW_TSET;   // what a merge rewrites
+
 template <int A, int M>
 struct Env {
-  int ap[A], ah[A];                                   // agent cell (x | y<<4), held group (-1 none)
-  int ip[M], ist[M], ig[M], iho[M], isq[M], its[M];   // item cell, chopped, group, holder, rank, type-set
+  int ap[A], ahp[A];   // agent cell (x | y<<4); held group + 1 (0 = empty hands)
+  int iw[M];           // packed item words
   int t, completed, goalcnt, mctr, err;
 };
+
+__device__ __forceinline__ int ipos(int w) { return w & IW_POS; }
+__device__ __forceinline__ int ichop(int w) { return (w >> 8) & 1; }
+__device__ __forceinline__ int igrp(int w) { return (w >> 9) & 7; }
+__device__ __forceinline__ int iseq(int w) { return (w >> 16) & 255; }
+__device__ __forceinline__ int itset(int w) { return (w >> 24) & 15; }
+__device__ __forceinline__ int bfi(int mask, int a, int b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
 
 template <int A, int M>
 __device__ __forceinline__ void unpack(Env<A, M> &e, const int32_t *w) {
 #pragma unroll
   for (int a = 0; a < A; a++) {
     e.ap[a] = w[a] & 255;
-    e.ah[a] = ((w[a] >> 8) & 15) - 1;
+    e.ahp[a] = (w[a] >> 8) & 15;
   }
 #pragma unroll
-  for (int i = 0; i < M; i++) {
-    const int v = w[A + i];
-    e.ip[i] = v & 255;
-    e.ist[i] = (v >> 8) & 1;
-    e.ig[i] = (v >> 9) & 7;
-    e.iho[i] = ((v >> 12) & 7) - 1;
-    e.isq[i] = (v >> 16) & 255;
-    e.its[i] = (v >> 24) & 15;
-  }
+  for (int i = 0; i < M; i++) e.iw[i] = w[A + i];
   e.t = (w[0] >> 16) & 0xFFFF;
   e.mctr = (w[1] >> 16) & 255;
   e.err = (w[1] >> 24) & 255;
@@ -166,13 +176,11 @@ __device__ __forceinline__ void unpack(Env<A, M> &e, const int32_t *w) {
 template <int A, int M>
 __device__ __forceinline__ void pack(const Env<A, M> &e, int32_t *w) {
 #pragma unroll
-  for (int a = 0; a < A; a++) w[a] = e.ap[a] | ((e.ah[a] + 1) << 8);
+  for (int a = 0; a < A; a++) w[a] = e.ap[a] | (e.ahp[a] << 8);
   w[0] |= e.t << 16;
   w[1] |= (e.mctr << 16) | (e.err << 24);
 #pragma unroll
-  for (int i = 0; i < M; i++)
-    w[A + i] = e.ip[i] | (e.ist[i] << 8) | (e.ig[i] << 9) | ((e.iho[i] + 1) << 12) | (e.isq[i] << 16) |
-               (e.its[i] << 24);
+  for (int i = 0; i < M; i++) w[A + i] = e.iw[i];
   w[A + M] = e.completed;
   w[A + M + 1] = e.goalcnt;
 }
@@ -186,6 +194,43 @@ __device__ __forceinline__ int bit128(const uint64_t (&w)[2], int c) {
   return (int)((v >> (c & 63)) & 1);
 }
 __device__ __forceinline__ int item_type(const LevelHdr &L, int i) { return (L.item_types >> (4 * i)) & 15; }
+// tile type (OC_FLOOR / COUNTER / CUTBOARD / DELIVERY) of dense cell c
+__device__ __forceinline__ int cell_type(const LevelHdr &L, int c) {
+  if (L.ncells <= 64)  // uniform (compile-time in specialised builds): one 64-bit plane each
+    return (int)((L.cell_lo[0] >> c) & 1) | ((int)((L.cell_hi[0] >> c) & 1) << 1);
+  return bit128(L.cell_lo, c) | (bit128(L.cell_hi, c) << 1);
+}
+
+// Every border cell of the map is a non-Floor tile: agents (always on Floor) can then never
+// propose a cell outside the map, so the proposal needs no bounds test, no clamp and no
+// OC_ERR_OOB path.  True for all fixed levels of the reference; decided at compile time in a
+// per-level specialised build, never assumed by the generic library.
+constexpr bool border_closed(const LevelHdr &L) {
+  for (int y = 0; y < L.H; y++)
+    for (int x = 0; x < L.W; x++)
+      if (x == 0 || y == 0 || x == L.W - 1 || y == L.H - 1) {
+        const int c = y * L.W + x;
+        if (!((L.nonfloor[c >> 6] >> (c & 63)) & 1)) return false;
+      }
+  return true;
+}
+#ifdef OC_SPECIALIZED
+constexpr bool OC_BORDER_CLOSED = border_closed(OC_SPEC_HDR);
+#else
+constexpr bool OC_BORDER_CLOSED = false;
+#endif
+
+// t / T as CPython computes it (overcooked_env.py:146: int / int, correctly rounded fp64)
+// without the 11-instruction fp64 division: q0 = t * RN(1/T), one FMA for the exact
+// residual, one FMA to correct.  Equal to the division for every 0 <= t, 1 <= T <= 65535
+// (all 4.3e9 pairs compared bit for bit: tests/test_host_cpu.py, tools/div_check.c).
+__device__ __forceinline__ double timestep_of(int t, const RunCfg &R) {
+  const double dt = (double)t;
+  if (R.T == 0) return t == 0 ? __builtin_nan("") : __builtin_inf();  // uniform; no time limit: t / 0.0
+  const double q0 = dt * R.inv_T;
+  const double r = __builtin_fma(-(double)R.T, q0, dt);
+  return __builtin_fma(r, R.inv_T, q0);
+}
 __device__ __forceinline__ int manhattan(int p, int q) { return iabs(px(p) - px(q)) + iabs(py(p) - py(q)); }
 
 // An [R][n] tensor of 4-byte (or 8-byte) elements addressed through a buffer resource:
@@ -397,20 +442,31 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   e.t = min(e.t + 1, 0xFFFF);  // :213 (16-bit field: saturates; max_num_timesteps <= 65535 is enforced)
 
   // ---- check_collisions (:578-613) on the ORIGINAL actions -------------------
-  int act[A], dx[A], dy[A], np[A];
+  int act[A], np[A], tgt_p[A], tgt_ct[A];   // action, proposed cell, interact()'s target cell and its tile type
 #pragma unroll
   for (int a = 0; a < A; a++) {
     int c = act_in[a];
-    c = (c < 0 || c > 4) ? OC_ACT_NOOP : c;
+    c = (unsigned)c > 4u ? OC_ACT_NOOP : c;
     act[a] = c;
-    dx[a] = (c == OC_ACT_RIGHT) - (c == OC_ACT_LEFT);
-    dy[a] = (c == OC_ACT_DOWN) - (c == OC_ACT_UP);
-    const int qx = px(e.ap[a]) + dx[a], qy = py(e.ap[a]) + dy[a];
-    const bool inb = (unsigned)qx < (unsigned)W && (unsigned)qy < (unsigned)H;
-    if (!inb) e.err |= OC_ERR_OOB;  // get_gridsquare_at asserts (utils/world.py:310-315)
-    const int qc = inb ? qy * W + qx : 0;
-    const bool blocked = !inb || bit128(L.nonfloor, qc);
-    np[a] = blocked ? e.ap[a] : (qx | (qy << 4));  // :551-559
+    if constexpr (OC_BORDER_CLOSED) {
+      // packed cell += {+16, -16, -1, +1, 0}: one signed byte per action code
+      constexpr uint64_t STEP = 0x0001FFF010ull;  // NOOP 00 | RIGHT 01 | LEFT ff | UP f0 | DOWN 10
+      const int q = e.ap[a] + (int)(int8_t)(STEP >> (8 * c));
+      tgt_p[a] = q;
+      tgt_ct[a] = cell_type(L, dense(L, q));
+      np[a] = tgt_ct[a] != OC_FLOOR ? e.ap[a] : q;  // :551-559
+    } else {
+      const int dx = (c == OC_ACT_RIGHT) - (c == OC_ACT_LEFT);
+      const int dy = (c == OC_ACT_DOWN) - (c == OC_ACT_UP);
+      const int qx = px(e.ap[a]) + dx, qy = py(e.ap[a]) + dy;
+      const bool inb = (unsigned)qx < (unsigned)W && (unsigned)qy < (unsigned)H;
+      if (!inb) e.err |= OC_ERR_OOB;  // get_gridsquare_at asserts (utils/world.py:310-315)
+      const int tx = min(max(qx, 0), W - 1), ty = min(max(qy, 0), H - 1);  // world.inbounds (world.py:317-320)
+      tgt_p[a] = tx | (ty << 4);
+      tgt_ct[a] = cell_type(L, ty * W + tx);
+      const bool blocked = !inb || (tgt_ct[a] != OC_FLOOR);
+      np[a] = blocked ? e.ap[a] : tgt_p[a];  // :551-559
+    }
   }
   bool ex[A];
 #pragma unroll
@@ -430,50 +486,50 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     }
 
   // ---- execute_navigation (:615-618): interact(), sequential in agent order ---
-  // decision phase + predicated per-item updates (utils/interact.py:4-75)
+  // decision phase + one bit-field insert per item (utils/interact.py:4-75)
 #pragma unroll
   for (int a = 0; a < A; a++) {
     const bool acting = ex[a] && act[a] != OC_ACT_NOOP;  // blocked -> (0,0) (:610-612); interact.py:12
+    // the agent's own cell has not changed since the proposal phase (only its own interact()
+    // moves it), so the target cell and its tile type computed there still hold
     const int pa = e.ap[a];
-    const int tx = min(max(px(pa) + dx[a], 0), W - 1);   // world.inbounds (world.py:317-320)
-    const int ty = min(max(py(pa) + dy[a], 0), H - 1);
-    const int tp = tx | (ty << 4);
-    const int tc = ty * W + tx;
-    const int ct = bit128(L.cell_lo, tc) | (bit128(L.cell_hi, tc) << 1);
-    const bool holding = e.ah[a] >= 0;
-    // the held Object (items with holder == a) and the unheld Object on the target cell
-    int held_n = 0, held_ts = 0, held_fresh = 0, held_seq = 0;
-    int tgt_any = 0, tgt_ts = 0, tgt_fresh = 0, og = 7;
+    const int tp = tgt_p[a], ct = tgt_ct[a];
+    const bool holding = e.ahp[a] != 0;
+    const int hold_code = (a + 1) << 12;
+    // the held Object (items with holder == a) and the unheld Object on the target cell, as
+    // ORs of their item words with bit 8 turned into "a food that is still fresh"
+    int held_or = 0, tgt_or = 0;
     bool mine[M], tgt[M];
 #pragma unroll
     for (int i = 0; i < M; i++) {
-      const int food_fresh = (item_type(L, i) != OC_PLATE) & (e.ist[i] ^ 1);
-      mine[i] = e.iho[i] == a;
-      tgt[i] = e.iho[i] < 0 && e.ip[i] == tp;
-      held_n += mine[i];
-      held_ts |= mine[i] ? e.its[i] : 0;
-      held_fresh |= mine[i] ? food_fresh : 0;
-      held_seq = mine[i] ? e.isq[i] : held_seq;
-      tgt_any |= tgt[i];
-      tgt_ts |= tgt[i] ? e.its[i] : 0;
-      tgt_fresh |= tgt[i] ? food_fresh : 0;
-      og = tgt[i] ? min(og, e.ig[i]) : og;
+      const int w = e.iw[i];
+      const int u = item_type(L, i) != OC_PLATE ? (w ^ IW_CHOP) : w;  // uniform choice; a Plate is never chopped
+      mine[i] = (w & IW_HOLD) == hold_code;
+      tgt[i] = (w & (IW_HOLD | IW_POS)) == tp;                         // unheld and on the target cell
+      held_or |= mine[i] ? u : 0;
+      tgt_or |= tgt[i] ? u : 0;
     }
+    const bool tgt_any = tgt_or != 0;                                   // tset of an item is never empty
+    const bool held_multi = (held_or & IW_TSET & ((held_or & IW_TSET) - (1 << 24))) != 0;  // > 1 content
+    const bool held_fresh = (held_or & IW_CHOP) != 0;
+    const bool any_fresh = ((held_or | tgt_or) & IW_CHOP) != 0;
+    const bool two_plates = ((held_or & tgt_or) >> (24 + OC_PLATE)) & 1;
     const bool nf = acting && ct != OC_FLOOR;
     const bool do_move = acting && ct == OC_FLOOR;                       // interact.py:19-20
     const bool at_deliv = ct == OC_DELIVERY;
-    const bool do_deliver = nf && holding && at_deliv && held_n > 1 && !held_fresh;   // :25-30, core.py:232-237
-    const bool mergeable = !((held_ts & tgt_ts) & PLATE_BIT) && !held_fresh && !tgt_fresh;  // core.py:240-257
+    const bool do_deliver = nf && holding && at_deliv && held_multi && !held_fresh;   // :25-30, core.py:232-237
+    const bool mergeable = !two_plates && !any_fresh;                                   // core.py:240-257
     const bool do_merge = nf && holding && !at_deliv && tgt_any && mergeable;         // :33-46
-    const bool chop_here = ct == OC_CUTBOARD && held_n == 1 && held_fresh;            // :52
+    const bool chop_here = ct == OC_CUTBOARD && !held_multi && held_fresh;            // :52
     const bool do_chop = nf && holding && !at_deliv && !tgt_any && chop_here;         // :52-54
     const bool do_drop = nf && holding && !at_deliv && !tgt_any && !chop_here;        // :56-57
     const bool do_pick = nf && !holding && !at_deliv && tgt_any && !((R.allergic >> a) & 1);  // :62-71, agent.py:296-298
     const bool put = do_deliver || do_drop;
     const bool take = do_merge || do_pick;
-    const int newg = min(e.ah[a] < 0 ? 7 : e.ah[a], og);
-    const int newseq = M + e.mctr;  // re-inserted under a new name: last in world order (world.py:236-237)
-    const int merged_ts = held_ts | tgt_ts;
+    const int newg = min(holding ? e.ahp[a] - 1 : 7, igrp(tgt_or));  // only used when `take` (then tgt_any)
+    // the merged Object: smallest item id as group, re-inserted under a new name = last in
+    // world order (world.py:236-237), union of the type sets
+    const int objf = ((held_or | tgt_or) & IW_TSET) | (newg << 9) | ((M + e.mctr) << 16);
     if (A > 2) {
       // World.remove(agent.holding) deletes by (name, location), last match
       // (world.py:239-247): with another agent on the same cell holding a same-named
@@ -481,22 +537,28 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
       // reference's store is corrupt from here on.  Flag it.
       bool alias = false;
 #pragma unroll
-      for (int j = 0; j < M; j++)
-        alias |= e.iho[j] >= 0 && e.iho[j] != a && e.ip[j] == pa && e.its[j] == held_ts && e.isq[j] > held_seq;
+      for (int j = 0; j < M; j++) {
+        const int w = e.iw[j];
+        alias |= (w & IW_HOLD) != 0 && (w & IW_HOLD) != hold_code && ipos(w) == pa &&
+                 ((w ^ held_or) & IW_TSET) == 0 && (w & IW_SEQ) > (held_or & IW_SEQ);
+      }
       if (do_merge && alias) e.err |= OC_ERR_ALIAS;
     }
+    // held items: cell <- target (move / put down), holder <- none (put down), object
+    // fields (merge), chopped (chop); target-cell items: cell <- agent, holder <- agent
+    // (merge / pick up), object fields (merge)
+    const int mask_m = ((do_move || put) ? IW_POS : 0) | (put ? IW_HOLD : 0) | (do_merge ? IW_OBJ : 0) |
+                       (do_chop ? IW_CHOP : 0);
+    const int mask_t = (take ? (IW_POS | IW_HOLD) : 0) | (do_merge ? IW_OBJ : 0);
+    const int val_m = tp | IW_CHOP | objf;
+    const int val_t = pa | hold_code | objf;
 #pragma unroll
     for (int i = 0; i < M; i++) {
-      const bool both = do_merge && (mine[i] || tgt[i]);
-      e.ip[i] = (mine[i] && (do_move || put)) ? tp : ((tgt[i] && take) ? pa : e.ip[i]);
-      e.iho[i] = (mine[i] && put) ? -1 : ((tgt[i] && take) ? a : e.iho[i]);
-      e.ig[i] = both ? newg : e.ig[i];
-      e.isq[i] = both ? newseq : e.isq[i];
-      e.its[i] = both ? merged_ts : e.its[i];
-      e.ist[i] = (do_chop && mine[i]) ? 1 : e.ist[i];
+      const int sel = mine[i] ? mask_m : (tgt[i] ? mask_t : 0);
+      e.iw[i] = bfi(sel, mine[i] ? val_m : val_t, e.iw[i]);
     }
     e.ap[a] = do_move ? tp : pa;  // agent.py:311-314
-    e.ah[a] = put ? -1 : (take ? newg : e.ah[a]);
+    e.ahp[a] = put ? 0 : (take ? newg + 1 : e.ahp[a]);
     e.mctr += do_merge ? 1 : 0;
   }
 
@@ -507,13 +569,17 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   // by construction (mergeable() required it).
   const int d0 = (int)L.deliv_pos[0];  // first Delivery tile only (:259,:402)
   int present = 0, at_delivery = 0;
+  bool rep_ok[M];   // item i represents its Object (group == i) and the Object is all-chopped
 #pragma unroll
   for (int i = 0; i < M; i++) {
-    const int tb = 1 << item_type(L, i);
-    const bool ok = e.ig[i] == i && (e.its[i] != tb || item_type(L, i) == OC_PLATE || e.ist[i]);
-    const int b = ok ? (1 << e.its[i]) : 0;
+    const int w = e.iw[i];
+    const bool rep = (w & IW_GRP) == (i << 9);
+    // a lone fresh food is the only Object that is not all-chopped
+    const bool lone_fresh = item_type(L, i) != OC_PLATE && (w & (IW_TSET | IW_CHOP)) == ((1 << item_type(L, i)) << 24);
+    rep_ok[i] = rep && !lone_fresh;
+    const int b = rep_ok[i] ? (1 << itset(w)) : 0;
     present |= b;
-    at_delivery |= (e.ip[i] == d0) ? b : 0;
+    at_delivery |= ipos(w) == d0 ? b : 0;
   }
   int cnt_mask = 0, del_mask = 0;
 #pragma unroll
@@ -547,15 +613,16 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     if (k < (int)L.ndel) {  // uniform
 #pragma unroll
       for (int i = 0; i < M; i++) {
-        const int tb = 1 << item_type(L, i);
-        const bool ok = e.ig[i] == i && e.its[i] == (int)L.del_tset[k] &&
-                        (e.its[i] != tb || item_type(L, i) == OC_PLATE || e.ist[i]);
+        const bool ok = rep_ok[i] && (e.iw[i] & IW_TSET) == ((int)L.del_tset[k] << 24);
         del_has[k] |= ok;
-        del_p[k] = ok ? e.ip[i] : del_p[k];
+        del_p[k] = ok ? ipos(e.iw[i]) : del_p[k];
       }
     }
   }
-  shaping_terms<B, M>(L, dist, quot, apb, e.ip, e.completed, del_has, del_p, s0, s1 OC_STAMP_PASS);
+  int ipb[M];
+#pragma unroll
+  for (int i = 0; i < M; i++) ipb[i] = ipos(e.iw[i]);
+  shaping_terms<B, M>(L, dist, quot, apb, ipb, e.completed, del_has, del_p, s0, s1 OC_STAMP_PASS);
 }
 
 // get_observation2 (gym_comm/envs/overcooked_env.py:105-159) for one viewer;
@@ -565,30 +632,35 @@ __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, i
                                         bool viewer_blind, bool ego_blind, int C, int comm0, int comm1,
                                         const OutRows &out, int row0) {
   const int vp = viewer == 0 ? e.ap[0] : e.ap[1];
-  const int vh = viewer == 0 ? e.ah[0] : e.ah[1];
+  const int vhp = viewer == 0 ? e.ahp[0] : e.ahp[1];
   const int vx = px(vp), vy = py(vp);
   int ddx[4], ddy[4], st[4], hid[4];
+  int loc[4];   // agent1_location, agent2_location
+  if (viewer_blind) {  // uniform: deltas and locations 0, everything hidden (:109,:139-143)
 #pragma unroll
-  for (int ch = 0; ch < 4; ch++) {
-    // last writer in world.objects order wins (:121-131): the item of this type
-    // whose Object has the highest rank
-    int best = -1, bp = 0, bs = 0;
+    for (int ch = 0; ch < 4; ch++) ddx[ch] = ddy[ch] = st[ch] = loc[ch] = 0, hid[ch] = 1;
+  } else {
 #pragma unroll
-    for (int i = 0; i < M; i++)
-      if (item_type(L, i) == ch) {  // uniform
-        const bool better = e.isq[i] > best;
-        best = better ? e.isq[i] : best;
-        bp = better ? e.ip[i] : bp;
-        bs = better ? e.ist[i] : bs;
-      }
-    const bool have = best >= 0 && !viewer_blind;
-    ddx[ch] = have ? px(bp) - vx : 0;
-    ddy[ch] = have ? py(bp) - vy : 0;
-    st[ch] = (have && ch != OC_PLATE) ? bs : 0;
-    const bool within = iabs(ddx[ch]) + iabs(ddy[ch]) <= radius;
-    hid[ch] = viewer_blind ? 1 : (within ? 0 : 1);  // :109,:133
-    ddx[ch] = within ? 0 : ddx[ch];                 // :135 (sic: zeroed when visible)
-    ddy[ch] = within ? 0 : ddy[ch];
+    for (int ch = 0; ch < 4; ch++) {
+      // last writer in world.objects order wins (:121-131): the item of this type
+      // whose Object has the highest rank
+      int bw = 0;
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < M; i++)
+        if (item_type(L, i) == ch) {  // uniform
+          bw = (!any || (e.iw[i] & IW_SEQ) > (bw & IW_SEQ)) ? e.iw[i] : bw;
+          any = true;
+        }
+      // an absent type keeps delta (0,0)
+      const int bx = any ? px(ipos(bw)) : vx, by = any ? py(ipos(bw)) : vy;
+      const bool within = (int)__sad(bx, vx, __sad(by, vy, 0u)) <= radius;   // |dx| + |dy|
+      hid[ch] = within ? 0 : 1;                       // :133
+      ddx[ch] = within ? 0 : bx - vx;                 // :135 (sic: zeroed when visible)
+      ddy[ch] = within ? 0 : by - vy;
+      st[ch] = (any && ch != OC_PLATE) ? ichop(bw) : 0;
+    }
+    loc[0] = px(e.ap[0]), loc[1] = py(e.ap[0]), loc[2] = px(e.ap[1]), loc[3] = py(e.ap[1]);
   }
 #define OUT(r_, v_) do { if (O8) out.st8((r_), (v_)); else out.st((r_), (v_)); } while (0)
   int row = row0;
@@ -601,11 +673,9 @@ __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, i
 #pragma unroll
   for (int ch = 0; ch < 4; ch++) OUT(row++, hid[ch]);
   for (int s = 0; s < L.S; s++) OUT(row++, (e.completed >> s) & 1);
-  OUT(row++, viewer_blind ? 0 : px(e.ap[0]));  // :139-143
-  OUT(row++, viewer_blind ? 0 : py(e.ap[0]));
-  OUT(row++, viewer_blind ? 0 : px(e.ap[1]));
-  OUT(row++, viewer_blind ? 0 : py(e.ap[1]));
-  OUT(row++, ego_blind ? 0 : (vh >= 0 ? 1 : 0));  // :154, gated on the EGO's BLIND flag
+#pragma unroll
+  for (int k = 0; k < 4; k++) OUT(row++, loc[k]);
+  OUT(row++, ego_blind ? 0 : (vhp != 0 ? 1 : 0));  // :154, gated on the EGO's BLIND flag
   OUT(row++, 0);
   for (int c = 0; c < C; c++) OUT(row++, comm0 == c ? 1 : 0);
   for (int c = 0; c < C; c++) OUT(row++, comm1 == c ? 1 : 0);
@@ -855,7 +925,7 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
 #pragma unroll
   for (int v = 0; v < 2; v++)
     env_obs<A, M, O8>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
-  Out(p.timestep, p.n, 1, i, 8).st_f64(0, (double)e.t / (double)p.R.T);  // overcooked_env.py:146
+  Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));  // overcooked_env.py:146
 }
 
 struct ImageArgs {
@@ -894,15 +964,15 @@ __global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
     for (int y = 0; y < H; y++) {
       const int c = y * W + x, cell = x | (y << 4);
       int plane[7];
-      plane[0] = bit128(L.cell_lo, c) | (bit128(L.cell_hi, c) << 1);
+      plane[0] = cell_type(L, c);
 #pragma unroll
       for (int k = 1; k < 7; k++) plane[k] = 0;
 #pragma unroll
       for (int m = 0; m < M; m++) {  // world order is irrelevant: one writer per (plane, cell) value
         const int t = item_type(L, m);
-        const int v = t == OC_PLATE ? 1 : e.ist[m] + 1;
+        const int v = t == OC_PLATE ? 1 : ichop(e.iw[m]) + 1;
 #pragma unroll
-        for (int k = 3; k < 7; k++) plane[k] = (t + 3 == k && e.ip[m] == cell) ? v : plane[k];
+        for (int k = 3; k < 7; k++) plane[k] = (t + 3 == k && ipos(e.iw[m]) == cell) ? v : plane[k];
       }
 #pragma unroll
       for (int a = 0; a < A; a++) plane[a + 1] = e.ap[a] == cell ? 1 : plane[a + 1];
@@ -915,8 +985,8 @@ __global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
                                                (int)((v * rows + (k * W + x) * H + y) * p.n), AUX_WT);
       }
     }
-  p.holding[i] = e.ah[0] >= 0;
-  p.holding[p.n + i] = e.ah[1] >= 0;
+  p.holding[i] = e.ahp[0] != 0;
+  p.holding[p.n + i] = e.ahp[1] != 0;
 }
 
 struct ResetArgs {
@@ -1035,7 +1105,7 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
     for (int v = 0; v < 2; v++)
       env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
                         v * F);
-    Out(p.timestep, p.n, 1, i, 8).st_f64(0, (double)e.t / (double)p.R.T);
+    Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
   }
   OC_STAMP(7);   // every store issued
   slot.add(p.metrics != nullptr, valid, done, success, reward, comp, err);
@@ -1133,6 +1203,7 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
   memset(&h, 0, sizeof(h));
   h.W = W; h.H = H; h.A = A; h.M = M; h.S = S; h.max_path = b[OC_LV_MAX_PATH]; h.ncells = nc;
   run.T = b[OC_LV_T];
+  run.inv_T = run.T ? 1.0 / (double)run.T : 0.0;
   run.allergic = (uint32_t)b[OC_LV_ALLERGIC];
   const int32_t *cells = b + b[OC_LV_OFF_CELLS];
   const int32_t *ag = b + b[OC_LV_OFF_AGENTS], *it = b + b[OC_LV_OFF_ITEMS];
