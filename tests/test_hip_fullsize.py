@@ -170,3 +170,51 @@ def test_lds_table_variant_in_subprocess():
     out = subprocess.run([sys.executable, "-c", _LDS_SNIPPET % (ROOT, os.path.join(ROOT, "tests"))],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "LDS-variant ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+_WT_SNIPPET = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from gym_comm_amd import compiler
+from gym_comm_amd.batched import BatchedOvercooked
+from oracle import oracle
+from hip_util import assert_snapshots_equal
+bits = lambda a: a.view(np.uint64)
+for level, spec, dt in (("open-divider_tomato", True, torch.int32), ("full-divider_salad", False, torch.int8)):
+    lv = compiler.compile_level(level, 2, 60)
+    n, steps, C = 1111, 130, 3
+    rng = np.random.default_rng(11)
+    acts = np.stack([rng.integers(0, 4, (steps, n)), rng.integers(0, C, (steps, n)),
+                     rng.integers(0, 4, (steps, n)), rng.integers(0, C, (steps, n))], axis=1).astype(np.int32)
+    env = BatchedOvercooked(lv, num_envs=n, num_communication=C, auto_reset=True, specialize_level=spec, obs_dtype=dt)
+    ora = oracle.OracleBatch(lv.blob, n, threads=4)
+    comm = np.zeros((2, n), np.int32)
+    a_d = torch.from_numpy(acts).cuda()
+    for k in range(steps):
+        o, t, r, d = env.multi_step(a_d[k])
+        oo, to, ro, do = ora.multi_step(acts[k], comm, 2, 0, C, auto_reset=True)
+        assert np.array_equal(o.cpu().numpy(), oo), (level, k)
+        assert np.array_equal(d.cpu().numpy(), do), (level, k)
+        assert np.array_equal(bits(r.cpu().numpy()), bits(ro)), (level, k)
+        assert np.array_equal(bits(t.cpu().numpy()), bits(to)), (level, k)
+    assert_snapshots_equal(env.snapshot(), ora.snapshot_all(), level)
+print("store-policy variant ok")
+"""
+
+
+@pytest.mark.parametrize("wt", ["0", "1"])
+def test_store_policy_variants_in_subprocess(wt):
+    """The launcher picks default-policy stores below 8192 envs and write-through (sc1)
+    stores from there on; OC_WRITE_THROUGH forces one of them per process.  Both variants
+    of the fused kernel (int32 and int8 observation rows) against the oracle at a size where
+    the forced variant is NOT the default one (wt=1 at n=1111); wt=0 doubles as the check
+    that the override is harmless."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, OC_WRITE_THROUGH=wt)
+    out = subprocess.run([sys.executable, "-c", _WT_SNIPPET % (ROOT, os.path.join(ROOT, "tests"))],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "store-policy variant ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

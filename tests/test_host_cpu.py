@@ -275,3 +275,15 @@ def test_env_args_json_loader(tmp_path):
     assert b.ego_config["ALLERGIC"] is True and b.ego_config["CAN_MOVE"] is False
     with pytest.raises(KeyError):
         load_env_args({"num_agents": 2})
+
+
+def test_two_fma_timestep_quotient_equals_division_exhaustively(tmp_path):
+    """timestep_of() in oc_kernels.hip forms t / T (overcooked_env.py:146) as
+    t * RN(1/T) + one FMA residual + one FMA correction instead of an fp64 division.
+    tools/div_check.c compares it with the correctly rounded quotient, bit for bit, for
+    every 0 <= t <= 65535 and 1 <= T <= 65535 (the ranges the 16-bit fields allow)."""
+    exe = str(tmp_path / "div_check")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tools", "div_check.c"),
+                           "-o", exe, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, check=True).stdout
+    assert "mismatches: 0" in out, out
