@@ -278,39 +278,50 @@ constexpr int AUX_WT = 16;      // sc1
 // given the agents' cells, the item cells, the completed flags and, per Deliver subtask, the
 // cell of its (all-chopped) object if one exists.  The int/int divisions of the reference
 // are entries of the quotient table k / MAX_PATH; sums run left to right in fp64.
+//
+// Split in two so the kernels can put their stores in between: shaping_issue() forms the
+// addresses and issues every path-distance load; the observation / state stores then keep
+// the memory pipeline busy while the loads are in flight; shaping_finish() consumes the
+// distances, looks the quotients up and does the fp64 sums.
+template <int B>
+struct ShapeIn {   // what shaping_finish() still needs of the pre-reset env
+  int ap[B];
+  int completed;
+  int del_has[MAX_DELS], del_p[MAX_DELS];
+};
+template <int B>
+struct ShapeLoads {   // raw path distances, in flight until shaping_finish()
+  int d_chop[3][B];
+  int d_pair[MAX_PAIRLK];
+  int d_del[MAX_DELS][B];
+  int d_tile[OC_MAX_DELIV][B];
+};
+
 template <int B, int M>
-__device__ __forceinline__ void shaping_terms(const LevelHdr &L, const uint8_t *__restrict__ dist,
-                                              const double *__restrict__ quot, const int (&ap)[B],
-                                              const int (&ipos)[M], int completed,
-                                              const int (&del_has)[MAX_DELS], const int (&del_p)[MAX_DELS],
-                                              double &s0, double &s1 OC_STAMP_PARAM) {
-  const int MAXP = L.max_path;
+__device__ __forceinline__ void shaping_issue(const LevelHdr &L, const uint8_t *__restrict__ dist,
+                                              const ShapeIn<B> &in, const int (&ipos)[M], ShapeLoads<B> &ld) {
   const int nc = L.ncells;
   int arow[B];
 #pragma unroll
-  for (int b = 0; b < B; b++) arow[b] = dense(L, ap[b]) * nc;
+  for (int b = 0; b < B; b++) arow[b] = dense(L, in.ap[b]) * nc;
   int ic[M];
 #pragma unroll
   for (int i = 0; i < M; i++) ic[i] = dense(L, ipos[i]);
-
-  // issue every distance lookup first, consume afterwards
-  int d_chop[3][B];
 #pragma unroll
   for (int f = 0; f < 3; f++) {
 #pragma unroll
-    for (int b = 0; b < B; b++) d_chop[f][b] = 0;
+    for (int b = 0; b < B; b++) ld.d_chop[f][b] = 0;
     if (L.chop_mask[f] != 0) {  // uniform
       int fc = 0;
 #pragma unroll
       for (int i = 0; i < M; i++) fc = ((int)L.food_item[f] == i) ? ic[i] : fc;
 #pragma unroll
-      for (int b = 0; b < B; b++) d_chop[f][b] = dist[arow[b] + fc];
+      for (int b = 0; b < B; b++) ld.d_chop[f][b] = dist[arow[b] + fc];
     }
   }
-  int d_pair[MAX_PAIRLK];
 #pragma unroll
   for (int k = 0; k < MAX_PAIRLK; k++) {
-    d_pair[k] = 0;
+    ld.d_pair[k] = 0;
     if (k < (int)L.npairlk) {  // uniform
       const int li = L.pairlk[k] & 15, lj = (L.pairlk[k] >> 4) & 15;
       int ci = 0, cj = 0;
@@ -319,33 +330,47 @@ __device__ __forceinline__ void shaping_terms(const LevelHdr &L, const uint8_t *
         ci = (li == i) ? ic[i] : ci;
         cj = (lj == i) ? ic[i] : cj;
       }
-      d_pair[k] = dist[ci * nc + cj];
+      ld.d_pair[k] = dist[ci * nc + cj];
     }
   }
-  int d_del[MAX_DELS][B];
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++) {
 #pragma unroll
-    for (int b = 0; b < B; b++) d_del[k][b] = 0;
+    for (int b = 0; b < B; b++) ld.d_del[k][b] = 0;
     if (k < (int)L.ndel) {  // uniform
-      const int mc = dense(L, del_p[k]);
+      const int mc = dense(L, in.del_p[k]);
 #pragma unroll
-      for (int b = 0; b < B; b++) d_del[k][b] = dist[arow[b] + mc];
+      for (int b = 0; b < B; b++) ld.d_del[k][b] = dist[arow[b] + mc];
     }
   }
+#pragma unroll
+  for (int k = 0; k < OC_MAX_DELIV; k++) {
+#pragma unroll
+    for (int b = 0; b < B; b++) ld.d_tile[k][b] = 0;
+    if (k < (int)L.ndeliv) {  // uniform
+      const int dc = dense(L, (int)L.deliv_pos[k]);
+#pragma unroll
+      for (int b = 0; b < B; b++) ld.d_tile[k][b] = dist[arow[b] + dc];
+    }
+  }
+}
+
+template <int B>
+__device__ __forceinline__ void shaping_finish(const LevelHdr &L, const double *__restrict__ quot,
+                                               const ShapeIn<B> &in, const ShapeLoads<B> &ld, double &s0,
+                                               double &s1 OC_STAMP_PARAM) {
+  const int MAXP = L.max_path;
+  const int completed = in.completed;
   int d_tile[B];  // min over Delivery tiles of path distance + manhattan (:382-388)
 #pragma unroll
   for (int b = 0; b < B; b++) d_tile[b] = 1 << 20;
 #pragma unroll
   for (int k = 0; k < OC_MAX_DELIV; k++)
     if (k < (int)L.ndeliv) {  // uniform
-      const int dp = (int)L.deliv_pos[k];
-      const int dc = dense(L, dp);
 #pragma unroll
-      for (int b = 0; b < B; b++) d_tile[b] = min(d_tile[b], (int)dist[arow[b] + dc] + manhattan(ap[b], dp));
+      for (int b = 0; b < B; b++)
+        d_tile[b] = min(d_tile[b], ld.d_tile[k][b] + manhattan(in.ap[b], (int)L.deliv_pos[k]));
     }
-
-  OC_STAMP(3);   // distance lookups issued
   // Chop term (:278-304)
   int nchop = 0;
   int mind[B];
@@ -357,7 +382,7 @@ __device__ __forceinline__ void shaping_terms(const LevelHdr &L, const uint8_t *
       const int open = __popc((int)L.chop_mask[f] & ~completed);
       nchop += open;
 #pragma unroll
-      for (int b = 0; b < B; b++) mind[b] = open ? min(mind[b], d_chop[f][b]) : mind[b];
+      for (int b = 0; b < B; b++) mind[b] = open ? min(mind[b], ld.d_chop[f][b]) : mind[b];
     }
   // pair term (:319-363): agent independent
   int npairs = (int)L.pair_static_max;
@@ -367,7 +392,7 @@ __device__ __forceinline__ void shaping_terms(const LevelHdr &L, const uint8_t *
 #pragma unroll
     for (int k = 0; k < MAX_PAIRLK; k++)
       if (k < (int)L.npairlk) {  // uniform
-        cur = min(cur, d_pair[k]);
+        cur = min(cur, ld.d_pair[k]);
         if ((L.pairlk[k] >> 8) & 1) {  // uniform: last lookup of this name pair
           const bool keep = cur != 0;    // a zero distance is not appended (:351-352)
           npairs += keep ? 1 : 0;
@@ -390,12 +415,12 @@ __device__ __forceinline__ void shaping_terms(const LevelHdr &L, const uint8_t *
       kq_del[k][b] = 0;
       del_direct[k][b] = false;
       if (k < (int)L.ndel) {
-        const int d = d_del[k][b] + manhattan(ap[b], del_p[k]);
+        const int d = ld.d_del[k][b] + manhattan(in.ap[b], in.del_p[k]);
         del_direct[k][b] = d == 0;                 // the agent holds it (:381)
         kq_del[k][b] = d == 0 ? d_tile[b] : d;
       }
     }
-  OC_STAMP(4);   // distances consumed
+  OC_STAMP(5);   // distances consumed
   const int qmax = (int)L.nquot - 1;
   double q_chop[B], q_pair, q_del[MAX_DELS][B];
 #pragma unroll
@@ -406,7 +431,6 @@ __device__ __forceinline__ void shaping_terms(const LevelHdr &L, const uint8_t *
 #pragma unroll
     for (int b = 0; b < B; b++) q_del[k][b] = (k < (int)L.ndel) ? quot[min(kq_del[k][b], qmax)] : 0.0;
 
-  OC_STAMP(5);   // quotient loads issued
   double tot[B];
 #pragma unroll
   for (int b = 0; b < B; b++) {
@@ -420,7 +444,7 @@ __device__ __forceinline__ void shaping_terms(const LevelHdr &L, const uint8_t *
       const bool open = !((completed >> L.del_bit[k]) & 1);
 #pragma unroll
       for (int b = 0; b < B; b++) {
-        const double add = !del_has[k] ? 2.0 : (del_direct[k][b] ? q_del[k][b] : q_del[k][b] + 1.0);
+        const double add = !in.del_has[k] ? 2.0 : (del_direct[k][b] ? q_del[k][b] : q_del[k][b] + 1.0);
         tot[b] = open ? tot[b] + add : tot[b];
       }
     }
@@ -433,11 +457,14 @@ __device__ __forceinline__ void shaping_terms(const LevelHdr &L, const uint8_t *
 // one environment tick: OvercookedEnvironment.step
 // (gym_cooking/envs/overcooked_environment.py:211-241)
 // ---------------------------------------------------------------------------
+// Everything up to done/reward, plus the address formation and the loads of the reward
+// shaping (shaping_issue); the caller stores what it has to store and then calls
+// shaping_finish(L, quot, sin, sld, ...).
 template <int A, int M>
 __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
-                                         const double *__restrict__ quot, Env<A, M> &e,
-                                         const int (&act_in)[A], int &reward, int &done, int &success,
-                                         double &s0, double &s1 OC_STAMP_PARAM) {
+                                         Env<A, M> &e, const int (&act_in)[A], int &reward, int &done,
+                                         int &success, ShapeIn<(A < 2 ? A : 2)> &sin,
+                                         ShapeLoads<(A < 2 ? A : 2)> &sld OC_STAMP_PARAM) {
   const int W = L.W, H = L.H;
   e.t = min(e.t + 1, 0xFFFF);  // :213 (16-bit field: saturates; max_num_timesteps <= 65535 is enforced)
 
@@ -600,29 +627,29 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   done = (timeout || all_delivered) ? 1 : 0;
   success = (!timeout && all_delivered) ? 1 : 0;
 
-  // ---- calculate_reward_shaping for sim agents 0 and 1 (:272-397) ------------
+  // ---- calculate_reward_shaping for sim agents 0 and 1 (:272-397): inputs + loads ----
   constexpr int B = A < 2 ? A : 2;
-  int apb[B];
 #pragma unroll
-  for (int b = 0; b < B; b++) apb[b] = e.ap[b];
-  int del_has[MAX_DELS], del_p[MAX_DELS];
+  for (int b = 0; b < B; b++) sin.ap[b] = e.ap[b];
+  sin.completed = e.completed;
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++) {
-    del_has[k] = 0;
-    del_p[k] = 0;
+    sin.del_has[k] = 0;
+    sin.del_p[k] = 0;
     if (k < (int)L.ndel) {  // uniform
 #pragma unroll
       for (int i = 0; i < M; i++) {
         const bool ok = rep_ok[i] && (e.iw[i] & IW_TSET) == ((int)L.del_tset[k] << 24);
-        del_has[k] |= ok;
-        del_p[k] = ok ? ipos(e.iw[i]) : del_p[k];
+        sin.del_has[k] |= ok;
+        sin.del_p[k] = ok ? ipos(e.iw[i]) : sin.del_p[k];
       }
     }
   }
   int ipb[M];
 #pragma unroll
   for (int i = 0; i < M; i++) ipb[i] = ipos(e.iw[i]);
-  shaping_terms<B, M>(L, dist, quot, apb, ipb, e.completed, del_has, del_p, s0, s1 OC_STAMP_PASS);
+  shaping_issue<B, M>(L, dist, sin, ipb, sld);
+  OC_STAMP(3);   // done/reward computed, distance loads issued
 }
 
 // get_observation2 (gym_comm/envs/overcooked_env.py:105-159) for one viewer;
@@ -868,18 +895,17 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs p) {
     Env<A, M> e;
     unpack<A, M>(e, w);
     const int err_before = e.err;
-    double s0, s1;
+    constexpr int B = A < 2 ? A : 2;
+    ShapeIn<B> sin;
+    ShapeLoads<B> sld;
 #ifdef OC_STAMPS
     unsigned long long oc_tt[16];
 #endif
-    env_step<A, M>(L, p.R, tb.dist, tb.quot, e, act, reward, done, success, s0, s1 OC_STAMP_PASS);
+    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     Out(p.reward, p.n, 1, i).st(0, reward);
     Out(p.done, p.n, 1, i).st(0, done);
-    const Out sh(p.shaping, p.n, 2, i, 8);
-    sh.st_f64(0, s0);
-    sh.st_f64(1, s1);
     if (done && p.auto_reset) {
 #pragma unroll
       for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
@@ -889,6 +915,12 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs p) {
     }
 #pragma unroll
     for (int r = 0; r < WS; r++) st.st(r, w[r]);
+    // the stores above drain while the path distances arrive
+    double s0, s1;
+    shaping_finish<B>(L, tb.quot, sin, sld, s0, s1 OC_STAMP_PASS);
+    const Out sh(p.shaping, p.n, 2, i, 8);
+    sh.st_f64(0, s0);
+    sh.st_f64(1, s1);
   }
   slot.add(p.metrics != nullptr, valid, done, success, reward, comp, err);
 }
@@ -1078,11 +1110,11 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
     act[0] = p.cfg.ego_agent_idx == 0 ? em : am;
     act[1] = p.cfg.ego_agent_idx == 0 ? am : em;
     const int err_before = e.err;
-    double s0, s1;
-    env_step<A, M>(L, p.R, tb.dist, tb.quot, e, act, reward, done, success, s0, s1 OC_STAMP_PASS);
+    ShapeIn<2> sin;
+    ShapeLoads<2> sld;
+    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
-    Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
     Out(p.done, p.n, 1, i).st(0, done);
 #ifndef OC_STAMPS
     if (p.sparse != nullptr) Out(p.sparse, p.n, 1, i).st(0, reward);
@@ -1106,6 +1138,11 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
       env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
                         v * F);
     Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
+    OC_STAMP(4);   // state and observation stores issued
+    // ... and they drain while the path distances arrive and the shaping is summed
+    double s0, s1;
+    shaping_finish<2>(L, tb.quot, sin, sld, s0, s1 OC_STAMP_PASS);
+    Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
   }
   OC_STAMP(7);   // every store issued
   slot.add(p.metrics != nullptr, valid, done, success, reward, comp, err);

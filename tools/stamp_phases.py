@@ -13,8 +13,8 @@ import torch
 from gym_comm_amd.batched import BatchedOvercooked
 
 NAMES = ["start->state+actions in regs", "collisions+interact", "done/reward + issue distance loads",
-         "distances arrive + integer shaping", "issue quotient loads", "quotients arrive + fp64 sums",
-         "auto-reset, state store, obs x2, issue stores", "metrics"]
+         "auto-reset, state store, obs x2 (stores issued)", "distances arrive + integer shaping",
+         "quotient loads + fp64 sums", "shaped reward stored", "metrics"]
 
 
 def main():
