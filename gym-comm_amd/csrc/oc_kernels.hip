@@ -709,16 +709,25 @@ __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, i
 #undef OUT
 }
 
-// Sum over the wave of a small non-negative per-lane integer (< 2^BITS): one ballot +
-// scalar popcount per bit -- no cross-lane shuffles, a handful of SALU ops.
-template <int BITS>
-__device__ __forceinline__ int wave_sum_small(int v) {
-  int s = 0;
-#pragma unroll
-  for (int b = 0; b < BITS; b++) s += __popcll(__ballot((v >> b) & 1)) << b;
-  return s;
+// Sum of a per-lane integer over the 64 lanes of the wave, left in lane 63: an inclusive scan
+// inside each row of 16 lanes (row_shr 1/2/4/8, zero fill), then row 0 -> 1, 2 -> 3
+// (row_bcast:15) and rows 0-1 -> 2-3 (row_bcast:31).  Six DPP adds, no LDS, no SALU loop.
+__device__ __forceinline__ int wave_sum_lane63(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
+  return v;
 }
 
+// Per-wave metric accumulation: the six counters of a step are packed into two words per
+// lane (every field wide enough for a sum over 64 lanes), both words are summed across the
+// wave with DPP adds, the totals are read from lane 63 into SGPRs, split by scalar bit-field
+// extracts and written back into lanes 0..5, and lane k adds counter k to the wave's OWN
+// 64-byte slot of the metrics tensor (one load issued at kernel start, one store; no
+// atomics).  Must be called with all 64 lanes active.
 struct MetricsSlot {
   int64_t *p;
   int64_t old;
@@ -731,19 +740,24 @@ struct MetricsSlot {
   __device__ __forceinline__ void add(bool has_metrics, bool valid, int done, int success, int reward,
                                       int completed_bits, bool err) {
     if (!has_metrics) return;  // uniform
-    const int n_valid = __popcll(__ballot(valid));
-    const int n_done = __popcll(__ballot(valid && done));
-    const int n_succ = __popcll(__ballot(valid && success));
-    const int n_err = __popcll(__ballot(valid && err));
-    const int rsum = wave_sum_small<6>(valid ? reward : 0);   // reward <= 16 + 3 * MAX_DELS < 64
-    const int csum = wave_sum_small<5>((valid && done) ? __popc(completed_bits) : 0);
-    const int lane = threadIdx.x & 63;
-    const int v = lane == OC_MET_ENV_STEPS ? n_valid
-                : lane == OC_MET_EPISODES ? n_done
-                : lane == OC_MET_SUCCESSES ? n_succ
-                : lane == OC_MET_REWARD_SUM ? rsum
-                : lane == OC_MET_COMPLETED_SUM ? csum
-                : n_err;
+    const bool fin = valid && done;
+    // word A: reward (<= 16 + 3 * MAX_DELS < 64 -> 12-bit sum) | completed subtasks of a finished episode (<= 32 -> 11-bit sum)
+    // word B: valid | done | success | error, 7 bits each (a count up to 64)
+    const int a = (valid ? reward : 0) | ((fin ? __popc(completed_bits) : 0) << 12);
+    const int b = (valid ? 1 : 0) | ((fin ? 1 : 0) << 7) | (((valid && success) ? 1 : 0) << 14) |
+                  (((valid && err) ? 1 : 0) << 21);
+    const unsigned ta = (unsigned)__builtin_amdgcn_readlane(wave_sum_lane63(a), 63);
+    const unsigned tb = (unsigned)__builtin_amdgcn_readlane(wave_sum_lane63(b), 63);
+    // lane k picks counter k out of the two totals: a per-lane (word, offset, width) from
+    // three packed constants -- plain VALU selects, no divergent control flow
+    constexpr unsigned OFF = 0u | 7u << 5 | 14u << 10 | 0u << 15 | 12u << 20 | 21u << 25;    // 5 bits per lane
+    constexpr unsigned WID = 7u | 7u << 5 | 7u << 10 | 12u << 15 | 11u << 20 | 7u << 25;
+    static_assert(OC_MET_ENV_STEPS == 0 && OC_MET_EPISODES == 1 && OC_MET_SUCCESSES == 2 &&
+                  OC_MET_REWARD_SUM == 3 && OC_MET_COMPLETED_SUM == 4 && OC_MET_ERRORS == 5, "slot order");
+    const unsigned lane = threadIdx.x & 63, k5 = (lane < 6 ? lane : 0) * 5;
+    const unsigned off = (OFF >> k5) & 31, wid = (WID >> k5) & 31;
+    const unsigned src = (lane == OC_MET_REWARD_SUM || lane == OC_MET_COMPLETED_SUM) ? ta : tb;
+    const int v = (int)((src >> off) & ((1u << wid) - 1u));
     if (p) *p = old + v;
   }
 };

@@ -388,3 +388,25 @@ def test_int8_observation_rows_match_reference_golden(name, fused):
         for lane in (0, 64, 129):
             assert (oh[:, :, lane] == z["obs"][k]).all(), (k, lane)
         assert (bits(r.cpu().numpy()) == z["rew_bits"][k]).all(), k
+
+
+def test_all_six_metric_counters_on_a_known_rollout():
+    """Every per-wave counter (env_steps, episodes, successes, reward_sum,
+    completed_subtasks_sum, errors) against a rollout whose totals are known in closed form:
+    n envs play the scripted open-divider_tomato solve (rewards +1 +1 +3,
+    done and successful at step 23, all 3 subtasks completed) except every 7th env, which
+    stands still and times out at T = 24 (one step later: the time limit is tested before
+    the deliveries, overcooked_environment.py:245-249).  n = 1000 leaves a 40-lane tail wave."""
+    from hip_util import KAT1_TOMATO
+    from gym_comm_amd import compiler
+    n, T = 1000, len(KAT1_TOMATO) + 1
+    lv = compiler.compile_level("open-divider_tomato", 2, T)
+    idle = np.arange(n) % 7 == 3
+    env = _env(lv, n, auto_reset=True, num_communication=2)
+    for a0, a1 in KAT1_TOMATO + [(4, 4)]:
+        acts = np.stack([np.where(idle, 4, a0), np.where(idle, 4, a1)]).astype(np.int32)
+        env.step(torch.from_numpy(acts).cuda())
+    m = env.read_metrics()
+    solved = int((~idle).sum())
+    assert m == {"env_steps": n * T, "episodes": n, "successes": solved, "reward_sum": 5 * solved,
+                 "completed_subtasks_sum": 3 * solved, "errors": 0}, m
