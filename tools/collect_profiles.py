@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = {"tomato_n4096": ("open-divider_tomato", 2, 4096, "k_multi_step"),
        "salad_n32768": ("full-divider_salad", 2, 32768, "k_multi_step"),
        "tl3_n65536": ("partial-divider_tl", 3, 65536, "k_step"),
-       "tomato_n131072": ("open-divider_tomato", 2, 131072, "k_multi_step")}
+       "tomato_n131072": ("open-divider_tomato", 2, 131072, "k_multi_step"),
+       "eager_tomato_n4096": ("open-divider_tomato", 2, 4096, "k_multi_step")}
 
 
 def main():

@@ -21,6 +21,9 @@ for c in "${cfgs[@]}"; do
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_s_$name -o s -- python3 bench.py "$@" --steps 200 --warmup 20 --no-graph --no-cpu-baseline > /dev/null 2> $OUT/pmc_s_$name.log
   echo "pmc $name done"
 done
+# the 4096-env kernel once more with eager launches (no graph): back-to-back graph nodes
+# under the profiler's per-dispatch signals read ~1 us longer than the kernel itself
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_eager_tomato_n4096 -o s -- python3 bench.py --no-graph --steps 4096 --warmup 256 --no-cpu-baseline > $OUT/stats_eager_tomato_n4096.json 2> $OUT/stats_eager_tomato_n4096.log
 # keep only the small CSVs (the merge back is capped)
 find $OUT -name "*.db" -delete 2>/dev/null || true
 du -sh $OUT

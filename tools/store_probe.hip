@@ -22,6 +22,24 @@ __global__ void probe(const int *in, int *out, int n, int loads, int spin) {
   for (int r = 0; r < STORES; r++) __builtin_amdgcn_raw_buffer_store_b32(acc + r, rsrc, i * 4, r * n * 4, AUX);
 }
 
+// the same words as [STORES/4] groups of 4 rows, 16 bytes per lane, lanes contiguous
+// (layout [group][n][4]): a wave store covers 1 KiB of consecutive memory
+template <int STORES, int AUX>
+__global__ void probe4(const int *in, int *out, int n, int loads, int spin) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (i >= n) return;
+  int acc = 0;
+  for (int r = 0; r < loads; r++) acc += in[r * n + i];
+  for (int k = 0; k < spin; k++) acc = ((acc ^ k) + (acc >> 3)) | 1;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, n * STORES * 4, 0x00020000);
+  typedef int v4i __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int g = 0; g < STORES / 4; g++) {
+    v4i v = {acc + g, acc, acc + 1, acc + 2};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, i * 16, g * n * 16, AUX);
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int STORES, int LPW, int AUX>
@@ -42,6 +60,29 @@ int run(int n, int *in, int *out, hipStream_t s, int spin) {
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   printf("n=%6d  lanes/wave=%2d  waves=%5d  stores=%2d  aux=%2d  valu~%4d: %6.2f us per launch\n", n, LPW,
          (n + LPW - 1) / LPW, STORES, AUX, 3 * spin, ms * 1e3 / (20 * 256));
+  fflush(stdout);
+  CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+  return 0;
+}
+
+template <int STORES, int AUX>
+int run4(int n, int *in, int *out, hipStream_t s, int spin) {
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+  for (int k = 0; k < 256; k++)
+    hipLaunchKernelGGL((probe4<STORES, AUX>), dim3((n + 63) / 64), dim3(64), 0, s, in, out, n, 12, spin);
+  CK(hipStreamEndCapture(s, &g));
+  CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  for (int w = 0; w < 4; w++) CK(hipGraphLaunch(ge, s));
+  CK(hipStreamSynchronize(s));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  CK(hipEventRecord(a, s));
+  for (int w = 0; w < 20; w++) CK(hipGraphLaunch(ge, s));
+  CK(hipEventRecord(b, s));
+  CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  printf("n=%6d  [group][n][4] dwordx4 stores  words=%2d  aux=%2d  valu~%4d: %6.2f us per launch\n", n, STORES, AUX,
+         3 * spin, ms * 1e3 / (20 * 256));
   fflush(stdout);
   CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
   return 0;
@@ -74,6 +115,11 @@ int main() {
     run<76, 64, 16>(n, in, out, s, 0);
     run<76, 64, 17>(n, in, out, s, 0);
     run<76, 64, 3>(n, in, out, s, 0);
+    run4<76, 0>(n, in, out, s, 0);
+    run4<76, 16>(n, in, out, s, 0);
+    run4<76, 0>(n, in, out, s, 400);
+    run4<76, 16>(n, in, out, s, 400);
+    run<76, 64, 16>(n, in, out, s, 400);
     run<8, 64, 0>(n, in, out, s, 0);
     run<8, 64, 2>(n, in, out, s, 0);
     run<8, 64, 17>(n, in, out, s, 0);
