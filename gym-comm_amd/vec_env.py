@@ -67,6 +67,12 @@ class RandomPartner:
         cm = torch.randint(0, self.C, (n,), generator=self.gen, device=self.device, dtype=torch.int32)
         return torch.stack([mv, cm], dim=1)
 
+    def act_into(self, obs, move_row, comm_row):
+        """Same draw, written straight into the kernel's action rows (int32 [n] each): two
+        launches instead of four (no stack, no transpose-copy)."""
+        move_row.random_(0, 4, generator=self.gen)
+        comm_row.random_(0, self.C, generator=self.gen)
+
 
 class OvercookedVecEnv(_VecEnvBase):
     def __init__(self, arglist, num_envs, partner=None, device="cuda", terminal_obs=False,
@@ -95,14 +101,23 @@ class OvercookedVecEnv(_VecEnvBase):
         self._act = torch.zeros((4, num_envs), dtype=torch.int32, device=self._b.device)
         self._pending = None
         self._partner_obs = None
+        # the kernel overwrites the same observation rows every step, so the 11-key views of
+        # both viewers are built once (22 slice + transpose objects cost ~60 us per step otherwise)
+        self._views = [None, None]
+        self._infos = [{} for _ in range(num_envs)]      # reused; only finished envs are touched
+        self._dirty = []
+        self._dtype_groups = None
         self.episode_returns = torch.zeros(num_envs, dtype=torch.float64, device=self._b.device)
         self.episode_lengths = torch.zeros(num_envs, dtype=torch.int64, device=self._b.device)
 
     # -- tensors ---------------------------------------------------------------------
     def _obs_tensors(self, viewer):
-        """The 11 keys as [n, k] device tensors (views of the kernel's [k][n] rows)."""
-        d = self._b.obs_dict(viewer)
-        return {k: v.T for k, v in d.items()}
+        """The 11 keys as [n, k] device tensors (views of the kernel's [k][n] rows; the same
+        tensor objects every step -- the next step overwrites their contents)."""
+        if self._views[viewer] is None:
+            d = self._b.obs_dict(viewer)
+            self._views[viewer] = {k: v.T for k, v in d.items()}
+        return self._views[viewer]
 
     def reset_tensors(self):
         self._b.reset()
@@ -117,10 +132,13 @@ class OvercookedVecEnv(_VecEnvBase):
         tensors, shaped reward f64 [n], done int32 [n]) -- views that the next step
         overwrites."""
         b = self._b
-        pa = self.partner(self._partner_obs)
-        pa = torch.as_tensor(pa, device=b.device).to(torch.int32)
-        ea = torch.as_tensor(ego_actions, device=b.device).to(torch.int32)
-        torch.cat((ea.T, pa.T), dim=0, out=self._act)        # rows: ego move, ego comm, alt move, alt comm
+        # rows of the action tensor: ego move, ego comm, alt move, alt comm
+        if hasattr(self.partner, "act_into"):
+            self.partner.act_into(self._partner_obs, self._act[2], self._act[3])
+        else:
+            pa = torch.as_tensor(self.partner(self._partner_obs), device=b.device)
+            self._act[2:4].copy_(pa.T)
+        self._act[0:2].copy_(torch.as_tensor(ego_actions, device=b.device).T)
         term = None
         if self.terminal_obs:
             b.multi_step(self._act, auto_reset=False)
@@ -145,13 +163,28 @@ class OvercookedVecEnv(_VecEnvBase):
         return {k: v.cpu().numpy().astype(SPACE_DTYPE[k]) for k, v in obs.items()}
 
     def _ego_obs_numpy(self):
-        """The ego viewer's 11 keys on the host: the [F][n] rows are transposed on the GPU
-        and cross PCIe in ONE copy (plus the fp64 timestep row), then numpy column slices."""
+        """The ego viewer's 11 keys on the host.  The [F][n] rows are gathered by target dtype
+        (int64 / float32 / int8 as the declared spaces, overcooked_env.py:41-85), transposed and
+        cast on the GPU, and cross PCIe as three contiguous [n][k] blocks; the per-key arrays
+        are column views of those blocks (no host-side casts)."""
         b = self._b
-        rows = b.obs[0].T.contiguous().cpu().numpy()        # [n][F] int32
-        out = {"timestep": b.timestep.cpu().numpy().astype(np.float32).reshape(-1, 1)}
-        for k, (lo, hi) in b._layout.items():
-            out[k] = rows[:, lo:hi].astype(SPACE_DTYPE[k])
+        if self._dtype_groups is None:
+            groups = {}
+            for k, (lo, hi) in b._layout.items():
+                groups.setdefault(SPACE_DTYPE[k], []).append((k, lo, hi))
+            self._dtype_groups = []
+            for dt, keys in groups.items():
+                rows = torch.tensor([r for _, lo, hi in keys for r in range(lo, hi)], device=b.device)
+                cols, c = {}, 0
+                for k, lo, hi in keys:
+                    cols[k] = (c, c + hi - lo)
+                    c += hi - lo
+                self._dtype_groups.append((getattr(torch, np.dtype(dt).name), rows, cols))
+        out = {"timestep": b.timestep.to(torch.float32).cpu().numpy().reshape(-1, 1)}
+        for tdt, rows, cols in self._dtype_groups:
+            block = b.obs[0].index_select(0, rows).T.to(tdt).contiguous().cpu().numpy()   # [n][k]
+            for k, (lo, hi) in cols.items():
+                out[k] = block[:, lo:hi]
         return out
 
     def reset(self):
@@ -164,9 +197,12 @@ class OvercookedVecEnv(_VecEnvBase):
     def step_wait(self):
         obs, rew, done = self.step_tensors(torch.from_numpy(self._pending.astype(np.int32)))
         done_np = done.cpu().numpy().astype(bool)
-        rew_np = rew.cpu().numpy().astype(np.float32)
-        infos = [{} for _ in range(self.num_envs)]
+        rew_np = rew.to(torch.float32).cpu().numpy()
+        infos = self._infos                       # the same list every step (as DummyVecEnv's buf_infos)
+        for i in self._dirty:
+            infos[i] = {}
         idx = np.nonzero(done_np)[0]
+        self._dirty = idx.tolist()
         if len(idx):
             ret = self.episode_returns.cpu().numpy()
             ln = self.episode_lengths.cpu().numpy()
@@ -178,7 +214,7 @@ class OvercookedVecEnv(_VecEnvBase):
             m = done.bool()
             self.episode_returns[m] = 0
             self.episode_lengths[m] = 0
-        return self._ego_obs_numpy(), rew_np, done_np, infos
+        return self._ego_obs_numpy(), rew_np, done_np, list(infos)   # shallow copy: holders keep their dicts
 
     def close(self):
         pass
