@@ -787,18 +787,18 @@ __device__ __forceinline__ Tables stage_tables(const void *__restrict__ tables, 
   if constexpr (LDS) {
     extern __shared__ uint4 oc_lds[];
     const uint4 *src = (const uint4 *)tables;
-    uint4 t[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int idx = threadIdx.x + k * blockDim.x;
-      if (idx < n16) t[k] = src[idx];
-    }
+    // four named registers, not an array: a conditionally written array went to scratch
+    const int i0 = threadIdx.x, i1 = i0 + blockDim.x, i2 = i1 + blockDim.x, i3 = i2 + blockDim.x;
+    uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0, t3 = t0;
+    if (i0 < n16) t0 = src[i0];
+    if (i1 < n16) t1 = src[i1];
+    if (i2 < n16) t2 = src[i2];
+    if (i3 < n16) t3 = src[i3];
     for (int idx = threadIdx.x + 4 * blockDim.x; idx < n16; idx += blockDim.x) oc_lds[idx] = src[idx];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int idx = threadIdx.x + k * blockDim.x;
-      if (idx < n16) oc_lds[idx] = t[k];
-    }
+    if (i0 < n16) oc_lds[i0] = t0;
+    if (i1 < n16) oc_lds[i1] = t1;
+    if (i2 < n16) oc_lds[i2] = t2;
+    if (i3 < n16) oc_lds[i3] = t3;
     __syncthreads();
     tb.quot = (const double *)oc_lds;
     tb.dist = (const uint8_t *)oc_lds + quot_bytes;
