@@ -20,6 +20,7 @@ Deviations, all of them deliberate and stated:
   * the subtask order is canonical (compiler.canonical_subtasks) unless
     ``subtask_order=`` is given -- the reference's own order changes with PYTHONHASHSEED.
 """
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -190,6 +191,102 @@ class OvercookedEnvironment:
                 ox = x * scale + 2 + (k % 2) * (q + 2)
                 oy = y * scale + 2 + (k // 2) * (q + 2)
                 img[oy:oy + q, ox:ox + q] = col.astype(np.uint8)
+        return img
+
+    # -- sprite frames ------------------------------------------------
+    # misc/game/utils.py:4-9 (Color) and utils/agent.py:25 (COLORS)
+    _GAME_RGB = {"FLOOR": (245, 230, 210), "COUNTER": (220, 170, 110),
+                 "COUNTER_BORDER": (114, 93, 51), "DELIVERY": (96, 96, 96)}
+    _AGENT_COLOR = ["blue", "magenta", "yellow", "green"]
+    _sprite_cache = {}
+
+    @classmethod
+    def _sprite(cls, sprite_dir, name, size):
+        """RGBA sprite `name`.png scaled to size x size (nearest neighbour, as
+        pygame.transform.scale), cached."""
+        key = (sprite_dir, name, size)
+        if key not in cls._sprite_cache:
+            from PIL import Image
+            with Image.open(os.path.join(sprite_dir, name + ".png")) as im:
+                cls._sprite_cache[key] = np.asarray(
+                    im.convert("RGBA").resize((size, size), Image.NEAREST), dtype=np.uint8)
+        return cls._sprite_cache[key]
+
+    @staticmethod
+    def _blit(img, sprite, x, y):
+        """Alpha-blend an RGBA sprite onto the RGB frame with its top-left corner at (x, y),
+        clipped to the frame (pygame Surface.blit of a per-pixel-alpha image)."""
+        h, w = sprite.shape[:2]
+        x0, y0 = max(x, 0), max(y, 0)
+        x1, y1 = min(x + w, img.shape[1]), min(y + h, img.shape[0])
+        if x1 <= x0 or y1 <= y0:
+            return
+        sp = sprite[y0 - y:y1 - y, x0 - x:x1 - x].astype(np.int32)
+        a = sp[..., 3:4]
+        dst = img[y0:y1, x0:x1].astype(np.int32)
+        img[y0:y1, x0:x1] = ((sp[..., :3] * a + dst * (255 - a) + 127) // 255).astype(np.uint8)
+
+    def render_frame(self, sprite_dir=None, scale=80):
+        """(H*scale) x (W*scale) x 3 uint8 frame composed as the reference's pygame renderer
+        does (misc/game/game.py:55-158, Game.on_render): floor fill; Counter / Delivery /
+        Cutboard tiles; objects nobody holds (a Plate at tile size with its plated contents at
+        0.7 of it, centred); agents, and what each holds in the bottom-right quarter (0.5 of the
+        tile, plated contents at 0.7 of that).  The PNG sprites are the reference's own files
+        (gym_cooking/misc/game/graphics/*.png, not redistributed here): pass their directory as
+        `sprite_dir` or in OC_SPRITE_DIR.  Without sprites the result is render_rgb(scale).
+        pygame is absent from the build image, so pixel parity with the reference's frames is
+        unpinned; geometry and draw order follow the cited lines."""
+        sprite_dir = sprite_dir or os.environ.get("OC_SPRITE_DIR")
+        if not sprite_dir or not os.path.isdir(sprite_dir):
+            return self.render_rgb(scale)
+        lv = self._b.level
+        C = self._GAME_RGB
+        img = np.empty((lv.height * scale, lv.width * scale, 3), np.uint8)
+        img[:] = C["FLOOR"]                                                   # game.py:56
+        hold = int(0.5 * scale)                     # holding_size   (game.py:31,37)
+        cont = int(0.7 * scale)                     # container_size (game.py:32,38)
+        hold_cont = int(0.7 * hold)                 # holding_container_size (game.py:39)
+        for y in range(lv.height):                                           # draw_gridsquare, :79-96
+            for x in range(lv.width):
+                t = int(lv.cells[y][x])
+                if t == L.FLOOR:
+                    continue
+                px, py = x * scale, y * scale
+                tile = img[py:py + scale, px:px + scale]
+                if t == L.DELIVERY:
+                    tile[:] = C["DELIVERY"]
+                    self._blit(img, self._sprite(sprite_dir, "delivery", scale), px, py)
+                else:
+                    tile[:] = C["COUNTER"]
+                    tile[0, :] = tile[-1, :] = C["COUNTER_BORDER"]            # 1-pixel outline
+                    tile[:, 0] = tile[:, -1] = C["COUNTER_BORDER"]
+                    if t == L.CUTBOARD:
+                        self._blit(img, self._sprite(sprite_dir, "cutboard", scale), px, py)
+
+        def draw_object(o, size, inner, at, inner_at):                       # draw_object / draw_agent_object
+            names = [c.full_name for c in sorted(o.contents, key=lambda c: c.name)]
+            if "Plate" in names:
+                self._blit(img, self._sprite(sprite_dir, "Plate", size), *at)
+                rest = [n for n in names if n != "Plate"]
+                if rest:
+                    self._blit(img, self._sprite(sprite_dir, "-".join(rest), inner), *inner_at)
+            else:
+                self._blit(img, self._sprite(sprite_dir, "-".join(names), size), *at)
+
+        for o in self.world.objects_in_order:                                # :70-72
+            if not o.is_held:
+                x, y = o.location
+                off = int(scale * (1 - 0.7) / 2)                              # container_location, :142-145
+                draw_object(o, scale, cont, (x * scale, y * scale), (x * scale + off, y * scale + off))
+        for i, ag in enumerate(self.sim_agents):                             # draw_agent, :103-106
+            x, y = ag.location
+            self._blit(img, self._sprite(sprite_dir, "agent-" + self._AGENT_COLOR[i % 4], scale),
+                       x * scale, y * scale)
+            if ag.holding is not None:
+                off = int(scale * (1 - 0.5))                                  # holding_location, :137-140
+                off2 = int(scale * ((1 - 0.5) + (1 - 0.7) / 2 * 0.5))         # holding_container_location, :147-151
+                draw_object(ag.holding, hold, hold_cont, (x * scale + off, y * scale + off),
+                            (x * scale + off2, y * scale + off2))
         return img
 
     def display(self):

@@ -144,3 +144,49 @@ def test_spaces_description():
                     "is_hidden", "completed_subtasks", "agent1_location", "agent2_location",
                     "agent_is_holding", "agent1_comm", "agent2_comm"]
     assert list(getattr(act, "nvec")) == [4, 2]
+
+
+def test_sprite_frame_geometry_and_draw_order(tmp_path):
+    """render_frame(): compositing of misc/game/game.py:55-158 with sprites read from a
+    directory.  The reference's PNGs do not travel; solid-colour stand-ins (one colour per
+    sprite name, the Plate half transparent) pin the geometry: tile fills and outline, an
+    unheld item at tile size, what an agent holds in the bottom-right quarter, plated
+    contents at 0.7 of the plate, draw order tiles < items < agents < held."""
+    from PIL import Image
+    from hip_util import KAT1_TOMATO
+    from gym_comm_amd.envs import OvercookedEnvironment
+    rgb = {"delivery": (10, 10, 10), "cutboard": (20, 20, 20), "Plate": (200, 200, 255),
+           "FreshTomato": (255, 0, 0), "ChoppedTomato": (128, 0, 0), "FreshLettuce": (0, 255, 0),
+           "ChoppedLettuce": (0, 128, 0), "agent-blue": (0, 0, 255), "agent-magenta": (255, 0, 255)}
+    for name, c in rgb.items():
+        a = 128 if name == "Plate" else 255
+        Image.new("RGBA", (8, 8), c + (a,)).save(str(tmp_path / (name + ".png")))
+    env = OvercookedEnvironment(_arglist("open-divider_tomato", 2, 100))
+    S = 40
+    f0 = env.render_frame(str(tmp_path), scale=S)
+    assert f0.shape == (7 * S, 7 * S, 3) and f0.dtype == np.uint8
+    px = lambda f, x, y, dx=S // 2, dy=S // 2: tuple(int(v) for v in f[y * S + dy, x * S + dx])
+    assert px(f0, 1, 2) == (245, 230, 210)                      # Floor (Color.FLOOR)
+    assert px(f0, 0, 0, 0, 0) == (114, 93, 51)                  # Counter outline
+    assert px(f0, 0, 0) == (220, 170, 110)                      # Counter fill
+    a0, a1 = env.sim_agents[0].location, env.sim_agents[1].location
+    assert px(f0, *a0) == rgb["agent-blue"] and px(f0, *a1) == rgb["agent-magenta"]
+    items = {o.full_name: o.location for o in env.world.objects_in_order}
+    assert px(f0, *items["FreshTomato"]) == rgb["FreshTomato"]
+    plate = items["Plate"]
+    blend = tuple((c * 128 + b * 127 + 127) // 255 for c, b in zip(rgb["Plate"], (220, 170, 110)))
+    assert px(f0, *plate) == blend                               # half-transparent sprite over the Counter
+    # play the scripted solve until agent-1 holds Plate-ChoppedTomato (after step 16)
+    for a0c, a1c in KAT1_TOMATO[:16]:
+        env.step({"agent-0": NAV[a0c], "agent-1": NAV[a1c]})
+    ag = env.sim_agents[1]
+    assert ag.holding is not None and ag.holding.full_name == "ChoppedTomato-Plate"
+    f = env.render_frame(str(tmp_path), scale=S)
+    x, y = ag.location
+    assert px(f, x, y, S // 4, S // 4) == rgb["agent-magenta"]   # top-left quarter: the agent
+    # bottom-right quarter: the held plate (0.5 tile, blended over the agent), its contents at 0.7 of that
+    held_plate = tuple((c * 128 + b * 127 + 127) // 255 for c, b in zip(rgb["Plate"], rgb["agent-magenta"]))
+    assert px(f, x, y, S // 2 + 1, S // 2 + 1) == held_plate     # plate corner, outside the contents inset
+    assert px(f, x, y, 3 * S // 4, 3 * S // 4) == rgb["ChoppedTomato"]
+    # without a sprite directory the sprite-free frame comes back
+    assert env.render_frame(None, scale=8).shape == (56, 56, 3)
