@@ -180,7 +180,7 @@ def test_sprite_frame_geometry_and_draw_order(tmp_path):
     for a0c, a1c in KAT1_TOMATO[:16]:
         env.step({"agent-0": NAV[a0c], "agent-1": NAV[a1c]})
     ag = env.sim_agents[1]
-    assert ag.holding is not None and ag.holding.full_name == "ChoppedTomato-Plate"
+    assert ag.holding is not None and ag.holding.full_name == "Plate-ChoppedTomato"
     f = env.render_frame(str(tmp_path), scale=S)
     x, y = ag.location
     assert px(f, x, y, S // 4, S // 4) == rgb["agent-magenta"]   # top-left quarter: the agent
