@@ -2,7 +2,8 @@
 """Long randomized parity soak on a GPU box: every built-in fixed level x 2..4 agents and
 every random-* level, thousands of envs with per-env action streams, HIP vs the CPU oracle
 with a full state compare every step.  Not part of the test-suite (minutes, not seconds);
-run it when the kernels change:  python tools/soak.py [steps] [envs]"""
+run it when the kernels change:  python tools/soak.py [steps] [envs] [generic|spec]
+("spec" compiles a per-level specialised library for every configuration on first use)."""
 import os
 import sys
 import time
@@ -60,6 +61,7 @@ def run(level, A, T, n, steps, seed, spec):
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    use_spec = len(sys.argv) > 3 and sys.argv[3] == "spec"
     t0 = time.time()
     total = 0
     for name in sorted(levels.BUILTIN):
@@ -67,14 +69,15 @@ def main():
         for A in range(2, min(4, len(spec.agent_starts)) + 1):
             if name == "random-open-divider_salad_small_cramped":
                 continue        # agent 0 starts boxed in at (0,0): every move is out of bounds
-            rsum, flagged = run(name, A, 120, n, steps, 1000 + A, spec=False)
+            rsum, flagged = run(name, A, 120, n, steps, 1000 + A, spec=use_spec)
             total += n * steps
             print("%-46s A=%d  ok  reward_sum=%-6d flagged_env_steps=%-5d  (%.0fs)"
                   % (name, A, rsum, flagged, time.time() - t0), flush=True)
     # the out-of-bounds level: both sides must raise OC_ERR_OOB on the same envs
-    rsum, flagged = run("random-open-divider_salad_small_cramped", 2, 120, n, min(steps, 200), 7, spec=False)
+    rsum, flagged = run("random-open-divider_salad_small_cramped", 2, 120, n, min(steps, 200), 7, spec=use_spec)
     print("random-open-divider_salad_small_cramped        A=2  ok  flagged_env_steps=%d" % flagged)
-    print("soak ok: %d env-steps compared bit-exactly in %.0f s" % (total, time.time() - t0))
+    print("soak ok (%s kernels): %d env-steps compared bit-exactly in %.0f s"
+          % ("per-level specialised" if use_spec else "generic", total, time.time() - t0))
 
 
 if __name__ == "__main__":
