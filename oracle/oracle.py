@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OC_ORACLE_LIB selects another build of the same source, e.g. the ASan/UBSan one
-# (`make -C oracle asan`, tools/oracle_asan.sh)
+# (`make -C oracle asan`, tests/oracle_asan.sh)
 _LIB_PATH = os.environ.get("OC_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboc_oracle.so")
 _lib = None
 

@@ -2,7 +2,7 @@
 """Long randomized parity soak on a GPU box: every built-in fixed level x 2..4 agents and
 every random-* level, thousands of envs with per-env action streams, HIP vs the CPU oracle
 with a full state compare every step.  Not part of the test-suite (minutes, not seconds);
-run it when the kernels change:  python tools/soak.py [steps] [envs] [generic|spec]
+run it when the kernels change:  python tests/soak.py [steps] [envs] [generic|spec]
 ("spec" compiles a per-level specialised library for every configuration on first use)."""
 import os
 import sys
