@@ -886,20 +886,23 @@ struct StepArgs {
   int32_t auto_reset;
 };
 
+// (leading scalars: preloaded kernel arguments, see k_multi_step)
 template <int A, int M, bool LDS, bool WT>
-__global__ void __launch_bounds__(256) k_step(const StepArgs p) {
+__global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32_t *const actions_,
+                                              int64_t *const metrics_, const int64_t n_, const int32_t block_,
+                                              const StepArgs p) {
   using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < p.n;
+  const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
+  const bool valid = i < (int)n_;
   const Tables tb = stage_tables<LDS>(p.tables, p.n16, p.quot_bytes);
-  MetricsSlot slot(p.metrics, i);
+  MetricsSlot slot(metrics_, i);
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
     constexpr int WS = A + M + 2;
-    const Out st(p.state, p.n, WS, i);
-    const Rows ac(p.actions, p.n, A, i);
+    const Out st(state_, n_, WS, i);
+    const Rows ac(actions_, n_, A, i);
     int32_t w[WS];
 #pragma unroll
     for (int r = 0; r < WS; r++) w[r] = st.ld(r);
@@ -936,7 +939,7 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs p) {
     sh.st_f64(0, s0);
     sh.st_f64(1, s1);
   }
-  slot.add(p.metrics != nullptr, valid, done, success, reward, comp, err);
+  slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
 }
 
 struct ObsArgs {
@@ -1086,25 +1089,32 @@ struct MultiArgs {
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
 template <int M, bool LDS, bool O8, bool WT>
-__global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
+__global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
+                                                    int32_t *const comm_, int64_t *const metrics_,
+                                                    const int64_t n_, const int32_t block_,
+                                                    const MultiArgs p) {
+  // The six leading scalars repeat fields of `p` (and the workgroup size, which would
+  // otherwise come from the hidden arguments): as plain leading arguments they are preloaded
+  // into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, build.py), so the state
+  // and action loads are issued without first waiting for a scalar kernarg load.
   constexpr int A = 2;
   using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < p.n;
+  const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
+  const bool valid = i < (int)n_;
 #ifdef OC_STAMPS
   unsigned long long oc_tt[16];
   for (int k = 0; k < 16; k++) oc_tt[k] = 0;
 #endif
   OC_STAMP(0);
   const Tables tb = stage_tables<LDS>(p.tables, p.n16, p.quot_bytes);
-  MetricsSlot slot(p.metrics, i);
+  MetricsSlot slot(metrics_, i);
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
     constexpr int WS = A + M + 2;
-    const Out st(p.state, p.n, WS, i), cm(p.comm, p.n, 2, i);
-    const Rows ac(p.actions, p.n, 4, i);
+    const Out st(state_, n_, WS, i), cm(comm_, n_, 2, i);
+    const Rows ac(actions_, n_, 4, i);
     int32_t w[WS];
 #pragma unroll
     for (int r = 0; r < WS; r++) w[r] = st.ld(r);
@@ -1159,7 +1169,7 @@ __global__ void __launch_bounds__(256) k_multi_step(const MultiArgs p) {
     Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
   }
   OC_STAMP(7);   // every store issued
-  slot.add(p.metrics != nullptr, valid, done, success, reward, comp, err);
+  slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
   OC_STAMP(8);
 #ifdef OC_STAMPS
   // the sparse-reward pointer doubles as the debug buffer in this build: int64 [waves][16]
@@ -1186,16 +1196,31 @@ int block_size_for(int64_t n) {
 // rows are addressed with 32-bit byte offsets through a buffer descriptor
 bool fits_buffer(int64_t n, int64_t rows, int elem) { return n * rows * elem < (int64_t)0x7FFFFFFF; }
 
-template <typename Args, typename K>
-int launch(K kernel, const Args &args, int64_t n, void *stream, size_t lds_bytes = 0) {
+template <typename K, typename... Args>
+int launch_n(K kernel, int64_t n, void *stream, size_t lds_bytes, const Args &...args) {
   if (n == 0) return OC_OK;
   const int bs = block_size_for(n);
   const int64_t grid = (n + bs - 1) / bs;
   if (grid > 0x7FFFFFFF) return fail(OC_E_BADARG, "n too large");
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(bs), lds_bytes, (hipStream_t)stream, args);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(bs), lds_bytes, (hipStream_t)stream, args...);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "kernel launch");
   return OC_OK;
+}
+template <typename Args, typename K>
+int launch(K kernel, const Args &args, int64_t n, void *stream, size_t lds_bytes = 0) {
+  return launch_n(kernel, n, stream, lds_bytes, args);
+}
+// k_step / k_multi_step: hot scalars first (preloaded kernel arguments), then the full block
+template <typename K>
+int launch_st(K kernel, const StepArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
+  return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.metrics, a.n,
+                  (int32_t)block_size_for(n), a);
+}
+template <typename K>
+int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
+  return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.comm, a.metrics, a.n,
+                  (int32_t)block_size_for(n), a);
 }
 
 bool write_through(int64_t n) {
@@ -1500,16 +1525,16 @@ int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
   const size_t lds = (size_t)lv->n16 * 16;
   if (tables_in_lds(n)) {
-#define OC_X(AA, MM) return launch(k_step<AA, MM, true, false>, a, n, stream, lds)
+#define OC_X(AA, MM) return launch_st(k_step<AA, MM, true, false>, a, n, stream, lds)
     OC_FOR_AM(OC_X)
 #undef OC_X
   } else {
     if (write_through(n)) {
-#define OC_X(AA, MM) return launch(k_step<AA, MM, false, true>, a, n, stream, 0)
+#define OC_X(AA, MM) return launch_st(k_step<AA, MM, false, true>, a, n, stream, 0)
       OC_FOR_AM(OC_X)
 #undef OC_X
     }
-#define OC_X(AA, MM) return launch(k_step<AA, MM, false, false>, a, n, stream, 0)
+#define OC_X(AA, MM) return launch_st(k_step<AA, MM, false, false>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   }
@@ -1573,11 +1598,11 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   const bool wt = write_through(n);
 #define OC_MS(MM)                                                                     \
   do {                                                                                \
-    if (in_lds && !o8) return launch(k_multi_step<MM, true, false, false>, a, n, stream, lds);      \
-    if (o8) return wt ? launch(k_multi_step<MM, false, true, true>, a, n, stream, 0)                \
-                      : launch(k_multi_step<MM, false, true, false>, a, n, stream, 0);              \
-    return wt ? launch(k_multi_step<MM, false, false, true>, a, n, stream, 0)                       \
-              : launch(k_multi_step<MM, false, false, false>, a, n, stream, 0);                     \
+    if (in_lds && !o8) return launch_ms(k_multi_step<MM, true, false, false>, a, n, stream, lds);      \
+    if (o8) return wt ? launch_ms(k_multi_step<MM, false, true, true>, a, n, stream, 0)                \
+                      : launch_ms(k_multi_step<MM, false, true, false>, a, n, stream, 0);              \
+    return wt ? launch_ms(k_multi_step<MM, false, false, true>, a, n, stream, 0)                       \
+              : launch_ms(k_multi_step<MM, false, false, false>, a, n, stream, 0);                     \
   } while (0)
 #ifdef OC_SPECIALIZED
   OC_MS(OC_SPEC_HDR.M);
