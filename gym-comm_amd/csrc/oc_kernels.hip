@@ -188,7 +188,9 @@ __device__ __forceinline__ void pack(const Env<A, M> &e, int32_t *w) {
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int px(int p) { return p & 15; }
 __device__ __forceinline__ int py(int p) { return p >> 4; }
-__device__ __forceinline__ int dense(const LevelHdr &L, int p) { return py(p) * L.W + px(p); }
+__device__ __forceinline__ int dense(const LevelHdr &L, int p) {
+  return (int)(__umul24((unsigned)py(p), (unsigned)L.W) + (unsigned)px(p));  // v_mad_u32_u24
+}
 __device__ __forceinline__ int bit128(const uint64_t (&w)[2], int c) {
   const uint64_t v = (c & 64) ? w[1] : w[0];
   return (int)((v >> (c & 63)) & 1);
@@ -300,19 +302,21 @@ struct ShapeLoads {   // raw path distances, in flight until shaping_finish()
 template <int B, int M>
 __device__ __forceinline__ void shaping_issue(const LevelHdr &L, const uint8_t *__restrict__ dist,
                                               const ShapeIn<B> &in, const int (&ipos)[M], ShapeLoads<B> &ld) {
-  const int nc = L.ncells;
-  int arow[B];
+  // table offsets are unsigned 24-bit products: full-rate v_mul_u32_u24 / v_mad_u32_u24 and a
+  // 32-bit offset on a scalar base (no 64-bit address arithmetic per lookup)
+  const unsigned nc = (unsigned)L.ncells;
+  unsigned arow[B];
 #pragma unroll
-  for (int b = 0; b < B; b++) arow[b] = dense(L, in.ap[b]) * nc;
-  int ic[M];
+  for (int b = 0; b < B; b++) arow[b] = __umul24((unsigned)dense(L, in.ap[b]), nc);
+  unsigned ic[M];
 #pragma unroll
-  for (int i = 0; i < M; i++) ic[i] = dense(L, ipos[i]);
+  for (int i = 0; i < M; i++) ic[i] = (unsigned)dense(L, ipos[i]);
 #pragma unroll
   for (int f = 0; f < 3; f++) {
 #pragma unroll
     for (int b = 0; b < B; b++) ld.d_chop[f][b] = 0;
     if (L.chop_mask[f] != 0) {  // uniform
-      int fc = 0;
+      unsigned fc = 0;
 #pragma unroll
       for (int i = 0; i < M; i++) fc = ((int)L.food_item[f] == i) ? ic[i] : fc;
 #pragma unroll
@@ -324,13 +328,13 @@ __device__ __forceinline__ void shaping_issue(const LevelHdr &L, const uint8_t *
     ld.d_pair[k] = 0;
     if (k < (int)L.npairlk) {  // uniform
       const int li = L.pairlk[k] & 15, lj = (L.pairlk[k] >> 4) & 15;
-      int ci = 0, cj = 0;
+      unsigned ci = 0, cj = 0;
 #pragma unroll
       for (int i = 0; i < M; i++) {
         ci = (li == i) ? ic[i] : ci;
         cj = (lj == i) ? ic[i] : cj;
       }
-      ld.d_pair[k] = dist[ci * nc + cj];
+      ld.d_pair[k] = dist[__umul24(ci, nc) + cj];
     }
   }
 #pragma unroll
@@ -338,7 +342,7 @@ __device__ __forceinline__ void shaping_issue(const LevelHdr &L, const uint8_t *
 #pragma unroll
     for (int b = 0; b < B; b++) ld.d_del[k][b] = 0;
     if (k < (int)L.ndel) {  // uniform
-      const int mc = dense(L, in.del_p[k]);
+      const unsigned mc = (unsigned)dense(L, in.del_p[k]);
 #pragma unroll
       for (int b = 0; b < B; b++) ld.d_del[k][b] = dist[arow[b] + mc];
     }
@@ -348,7 +352,7 @@ __device__ __forceinline__ void shaping_issue(const LevelHdr &L, const uint8_t *
 #pragma unroll
     for (int b = 0; b < B; b++) ld.d_tile[k][b] = 0;
     if (k < (int)L.ndeliv) {  // uniform
-      const int dc = dense(L, (int)L.deliv_pos[k]);
+      const unsigned dc = (unsigned)dense(L, (int)L.deliv_pos[k]);
 #pragma unroll
       for (int b = 0; b < B; b++) ld.d_tile[k][b] = dist[arow[b] + dc];
     }
@@ -424,12 +428,12 @@ __device__ __forceinline__ void shaping_finish(const LevelHdr &L, const double *
   const int qmax = (int)L.nquot - 1;
   double q_chop[B], q_pair, q_del[MAX_DELS][B];
 #pragma unroll
-  for (int b = 0; b < B; b++) q_chop[b] = quot[min(kq_chop[b], qmax)];
-  q_pair = quot[min(kq_pair, qmax)];
+  for (int b = 0; b < B; b++) q_chop[b] = quot[(unsigned)min(kq_chop[b], qmax)];
+  q_pair = quot[(unsigned)min(kq_pair, qmax)];
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++)
 #pragma unroll
-    for (int b = 0; b < B; b++) q_del[k][b] = (k < (int)L.ndel) ? quot[min(kq_del[k][b], qmax)] : 0.0;
+    for (int b = 0; b < B; b++) q_del[k][b] = (k < (int)L.ndel) ? quot[(unsigned)min(kq_del[k][b], qmax)] : 0.0;
 
   double tot[B];
 #pragma unroll
@@ -562,14 +566,23 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
       // (world.py:239-247): with another agent on the same cell holding a same-named
       // Object that sits later in world order it removes the wrong one and the
       // reference's store is corrupt from here on.  Flag it.
-      bool alias = false;
+      // Only reachable when another agent stands on this agent's cell (the 3-agent overlap
+      // quirk of check_collisions) while this one merges: one ballot skips the item scan for
+      // the whole wave in every other step.
+      bool shared = false;
 #pragma unroll
-      for (int j = 0; j < M; j++) {
-        const int w = e.iw[j];
-        alias |= (w & IW_HOLD) != 0 && (w & IW_HOLD) != hold_code && ipos(w) == pa &&
-                 ((w ^ held_or) & IW_TSET) == 0 && (w & IW_SEQ) > (held_or & IW_SEQ);
+      for (int b = 0; b < A; b++)
+        if (b != a) shared |= e.ap[b] == pa;
+      if (__ballot(shared && do_merge) != 0) {
+        bool alias = false;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+          const int w = e.iw[j];
+          alias |= (w & IW_HOLD) != 0 && (w & IW_HOLD) != hold_code && ipos(w) == pa &&
+                   ((w ^ held_or) & IW_TSET) == 0 && (w & IW_SEQ) > (held_or & IW_SEQ);
+        }
+        if (shared && do_merge && alias) e.err |= OC_ERR_ALIAS;
       }
-      if (do_merge && alias) e.err |= OC_ERR_ALIAS;
     }
     // held items: cell <- target (move / put down), holder <- none (put down), object
     // fields (merge), chopped (chop); target-cell items: cell <- agent, holder <- agent
