@@ -615,8 +615,8 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     const int w = e.iw[i];
     const bool rep = (w & IW_GRP) == (i << 9);
     // a lone fresh food is the only Object that is not all-chopped
-    const bool lone_fresh = item_type(L, i) != OC_PLATE && (w & (IW_TSET | IW_CHOP)) == ((1 << item_type(L, i)) << 24);
-    rep_ok[i] = rep && !lone_fresh;
+    const bool lone_fresh = (item_type(L, i) != OC_PLATE) & ((w & (IW_TSET | IW_CHOP)) == ((1 << item_type(L, i)) << 24));
+    rep_ok[i] = rep & !lone_fresh;
     const int b = rep_ok[i] ? (1 << itset(w)) : 0;
     present |= b;
     at_delivery |= ipos(w) == d0 ? b : 0;
@@ -652,7 +652,8 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     if (k < (int)L.ndel) {  // uniform
 #pragma unroll
       for (int i = 0; i < M; i++) {
-        const bool ok = rep_ok[i] && (e.iw[i] & IW_TSET) == ((int)L.del_tset[k] << 24);
+        // `&`, not `&&`: the short-circuit form became an exec-masked region per item
+        const bool ok = rep_ok[i] & ((e.iw[i] & IW_TSET) == ((int)L.del_tset[k] << 24));
         sin.del_has[k] |= ok;
         sin.del_p[k] = ok ? ipos(e.iw[i]) : sin.del_p[k];
       }
@@ -717,8 +718,15 @@ __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, i
   for (int k = 0; k < 4; k++) OUT(row++, loc[k]);
   OUT(row++, ego_blind ? 0 : (vhp != 0 ? 1 : 0));  // :154, gated on the EGO's BLIND flag
   OUT(row++, 0);
-  for (int c = 0; c < C; c++) OUT(row++, comm0 == c ? 1 : 0);
-  for (int c = 0; c < C; c++) OUT(row++, comm1 == c ? 1 : 0);
+  if (C == 2) {  // uniform; the BASELINE configuration: straight-line instead of four scalar loops
+    OUT(row++, comm0 == 0 ? 1 : 0);
+    OUT(row++, comm0 == 1 ? 1 : 0);
+    OUT(row++, comm1 == 0 ? 1 : 0);
+    OUT(row++, comm1 == 1 ? 1 : 0);
+  } else {
+    for (int c = 0; c < C; c++) OUT(row++, comm0 == c ? 1 : 0);
+    for (int c = 0; c < C; c++) OUT(row++, comm1 == c ? 1 : 0);
+  }
 #undef OUT
 }
 
