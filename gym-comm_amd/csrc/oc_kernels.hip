@@ -186,6 +186,16 @@ __device__ __forceinline__ void pack(const Env<A, M> &e, int32_t *w) {
 }
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+// |a - b| + c on unsigned operands in one instruction (hipcc expands __sad() into compare,
+// two subtracts, select and add)
+__device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ int manhattan(int p, int q) {   // packed cells x | y<<4
+  return (int)sad_u32((unsigned)(p & 15), (unsigned)(q & 15), sad_u32((unsigned)(p >> 4), (unsigned)(q >> 4), 0u));
+}
 __device__ __forceinline__ int px(int p) { return p & 15; }
 __device__ __forceinline__ int py(int p) { return p >> 4; }
 __device__ __forceinline__ int dense(const LevelHdr &L, int p) {
@@ -233,7 +243,7 @@ __device__ __forceinline__ double timestep_of(int t, const RunCfg &R) {
   const double r = __builtin_fma(-(double)R.T, q0, dt);
   return __builtin_fma(r, R.inv_T, q0);
 }
-__device__ __forceinline__ int manhattan(int p, int q) { return iabs(px(p) - px(q)) + iabs(py(p) - py(q)); }
+
 
 // An [R][n] tensor of 4-byte (or 8-byte) elements addressed through a buffer resource:
 // the per-lane part of the address is one 32-bit byte offset (voffset), the row offset is
@@ -438,9 +448,10 @@ __device__ __forceinline__ void shaping_finish(const LevelHdr &L, const double *
   double tot[B];
 #pragma unroll
   for (int b = 0; b < B; b++) {
-    tot[b] = 0.0;
-    if (nchop) tot[b] += q_chop[b];
-    if (npairs) tot[b] += q_pair;
+    // `tot = 0; tot += x` of the reference is x itself (the quotients are never -0.0), so the
+    // first term is selected, not added to zero
+    tot[b] = nchop ? q_chop[b] : 0.0;
+    tot[b] = npairs ? tot[b] + q_pair : tot[b];
   }
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++)
@@ -695,7 +706,7 @@ __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, i
         }
       // an absent type keeps delta (0,0)
       const int bx = any ? px(ipos(bw)) : vx, by = any ? py(ipos(bw)) : vy;
-      const bool within = (int)__sad(bx, vx, __sad(by, vy, 0u)) <= radius;   // |dx| + |dy|
+      const bool within = (int)sad_u32(bx, vx, sad_u32(by, vy, 0u)) <= radius;   // |dx| + |dy|
       hid[ch] = within ? 0 : 1;                       // :133
       ddx[ch] = within ? 0 : bx - vx;                 // :135 (sic: zeroed when visible)
       ddy[ch] = within ? 0 : by - vy;
