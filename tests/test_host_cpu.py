@@ -287,3 +287,33 @@ def test_two_fma_timestep_quotient_equals_division_exhaustively(tmp_path):
                            "-o", exe, "-lm"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300, check=True).stdout
     assert "mismatches: 0" in out, out
+
+
+def test_no_kernel_spills_to_scratch(tmp_path):
+    """Register budget of the hot kernels: the per-level specialised build of the BASELINE
+    level keeps every kernel's state in VGPRs -- no scratch (a conditionally written local
+    array once sent the LDS variant there) and at most 128 VGPRs (the launch geometry assumes
+    one or two waves per SIMD, but never a spill)."""
+    import shutil
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    from gym_comm_amd import build, compiler, specialize
+    lv = compiler.compile_level("open-divider_tomato", 2, 500)
+    hdr = tmp_path / "spec.h"
+    hdr.write_text(specialize.spec_header_text(lv.blob))
+    asm = tmp_path / "k.s"
+    cmd = [build.hipcc_path(), "--offload-arch=" + build.ARCH]
+    cmd += [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
+    cmd += ["-DOC_SPECIALIZED", '-DOC_SPEC_FILE="%s"' % hdr, "-S", "--cuda-device-only", "-o", str(asm),
+            os.path.join(build.CSRC, "oc_kernels.hip")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    text = asm.read_text()
+    scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
+    vgprs = [int(v) for v in re.findall(r"; NumVgprs: (\d+)", text)]
+    assert len(scratch) >= 10 and len(scratch) == len(vgprs)
+    assert max(scratch) == 0, scratch
+    assert max(vgprs) <= 128, vgprs
+    # the fused step kernel's leading scalars arrive as preloaded kernel arguments
+    assert re.search(r"k_multi_step.*?\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", text, re.S)
+    pre = [int(v) for v in re.findall(r"\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", text)]
+    assert max(pre) >= 10, pre
