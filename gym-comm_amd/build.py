@@ -42,11 +42,16 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
     cmd = [hipcc_path(), "--offload-arch=" + ARCH] + FLAGS + list(extra_flags)
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    tmp = "%s.%d.tmp" % (LIB, os.getpid())        # concurrent builders never share a temporary
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

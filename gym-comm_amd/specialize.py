@@ -76,16 +76,25 @@ def ensure(blob, verbose=False):
     except RuntimeError:
         return None
     os.makedirs(SPEC_DIR, exist_ok=True)
+    # several ranks may reach this point for the same level at once (one process per GPU):
+    # every writer uses its own temporary names and publishes with an atomic rename
     hdr = os.path.join(SPEC_DIR, "spec_%s.h" % key)
-    with open(hdr, "w") as f:
+    tmp_hdr = "%s.%d.tmp" % (hdr, os.getpid())
+    with open(tmp_hdr, "w") as f:
         f.write(text)
+    os.replace(tmp_hdr, hdr)
+    tmp_lib = "%s.%d.tmp" % (path, os.getpid())
     cmd = [hipcc, "--offload-arch=" + _build.ARCH] + _build.FLAGS
     cmd += ["-DOC_SPECIALIZED", '-DOC_SPEC_FILE="%s"' % hdr]
-    cmd += [os.path.join(_build.CSRC, s) for s in _build.SOURCES] + ["-o", path + ".tmp"]
+    cmd += [os.path.join(_build.CSRC, s) for s in _build.SOURCES] + ["-o", tmp_lib]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    os.replace(path + ".tmp", path)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp_lib, path)
+    finally:
+        if os.path.exists(tmp_lib):
+            os.remove(tmp_lib)
     return path
 
 
