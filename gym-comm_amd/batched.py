@@ -75,18 +75,25 @@ class BatchedOvercooked:
         self._h = h
         self.W_state = self._L.oc_state_words(h)
         self.F = self._L.oc_obs_rows(h, self.C)
-        i32 = dict(dtype=torch.int32, device=self.device)
         n = self.n
-        self.state = torch.zeros((self.W_state, n), **i32)
-        self.reward = torch.zeros(n, **i32)
-        self.done = torch.zeros(n, **i32)
-        self.shaping = torch.zeros((2, n), dtype=torch.float64, device=self.device)
-        self.comm = torch.zeros((2, n), **i32)                 # one-hot(0) (overcooked_env.py:89-91)
         if obs_dtype not in (torch.int32, torch.int8):
             raise ValueError("obs_dtype must be torch.int32 or torch.int8")
-        self.obs = torch.zeros((2, self.F, n), dtype=obs_dtype, device=self.device)
-        self.timestep = torch.zeros(n, dtype=torch.float64, device=self.device)
-        self.shaped_reward = torch.zeros(n, dtype=torch.float64, device=self.device)
+        # Every tensor a step reads or writes is a view of ONE device allocation (each view
+        # 256-byte aligned): a host consumer fetches the whole step -- state, rewards, done,
+        # observations -- with a single device->host copy (`fetch()`), instead of one per tensor.
+        spec = [("state", (self.W_state, n), torch.int32), ("reward", (n,), torch.int32),
+                ("done", (n,), torch.int32), ("shaping", (2, n), torch.float64),
+                ("comm", (2, n), torch.int32),                  # one-hot(0) (overcooked_env.py:89-91)
+                ("obs", (2, self.F, n), obs_dtype), ("timestep", (n,), torch.float64),
+                ("shaped_reward", (n,), torch.float64)]
+        self._arena_layout, off = {}, 0
+        for name, shape, dt in spec:
+            nb = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            self._arena_layout[name] = (off, nb, shape, dt)
+            off += (nb + 255) // 256 * 256
+        self._arena = torch.zeros(max(off, 256), dtype=torch.uint8, device=self.device)
+        for name, (o, nb, shape, dt) in self._arena_layout.items():
+            setattr(self, name, self._arena[o:o + nb].view(dt).view(shape))
         self.metrics = (torch.zeros((self._L.oc_metrics_slots(n), 8), dtype=torch.int64,
                                     device=self.device) if track_metrics else None)
         self._obs_cfg = _lib.ObsCfg(int(fow_radius),
@@ -249,6 +256,16 @@ class BatchedOvercooked:
     def snapshot(self):
         """Named fields of every env's state (host numpy), see state.unpack_state."""
         return unpack_state(self.state.cpu().numpy(), self.A, self.M, self.S)
+
+    def fetch(self):
+        """ONE device->host copy of everything a step produced: returns {name: numpy view}
+        for state, reward, done, shaping, comm, obs, timestep, shaped_reward (host copies
+        with the device tensors' shapes and dtypes).  Synchronises with the stream."""
+        host = self._arena.cpu().numpy()
+        out = {}
+        for name, (o, nb, shape, dt) in self._arena_layout.items():
+            out[name] = host[o:o + nb].view(getattr(np, str(dt).replace("torch.", ""))).reshape(shape)
+        return out
 
     def metrics_vector(self):
         """int64[8] totals (sum over the per-wave slots), on the device."""

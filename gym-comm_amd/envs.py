@@ -108,12 +108,13 @@ class OvercookedEnvironment:
             device=device, subtask_order=subtask_order, placements=placements,
             level_dir=level_dir, auto_reset=False, track_metrics=False)
         lv = self._b.level
-        self.world = SimpleNamespace(width=lv.width, height=lv.height,
-                                     perimeter=2 * (lv.width + lv.height), arglist=arglist)
+        self._stale, self._pending_words = False, None
+        self._v_world = SimpleNamespace(width=lv.width, height=lv.height,
+                                        perimeter=2 * (lv.width + lv.height), arglist=arglist)
         self.recipes = list(lv.recipes)
         self.all_subtasks = [s.name for s in lv.subtasks]
-        self.sim_agents = [_SimAgent(i, self._b.ego_config if i == 0 else self._b.partner_config)
-                           for i in range(lv.num_agents)]
+        self._v_sim_agents = [_SimAgent(i, self._b.ego_config if i == 0 else self._b.partner_config)
+                              for i in range(lv.num_agents)]
         self.termination_info = ""
         self.successful = False
         self.collisions = []
@@ -122,12 +123,40 @@ class OvercookedEnvironment:
         self.reset()
 
     # -- state mirror ------------------------------------------------------------
-    def _sync(self):
+    # The reference's attributes (t, completed_subtasks, goal_objects_count, world, sim_agents,
+    # rep) are rebuilt from the packed state words only when somebody reads them: the wrapper's
+    # multi_step() hands over the words it fetched anyway (_mark_stale) and a training loop
+    # that never looks at base_env pays nothing for the mirror.
+    _LAZY = ("t", "completed_subtasks", "goal_objects_count", "rep", "sim_agents", "world", "_error")
+
+    def __getattr__(self, name):
+        if name in OvercookedEnvironment._LAZY:
+            self._materialize()
+            try:
+                return self.__dict__["_v_" + name]
+            except KeyError:
+                pass
+        raise AttributeError(name)
+
+    def _mark_stale(self, words):
+        """words: host copy of this env's packed state, int32 [A+M+2][1]."""
+        self._pending_words = np.array(words, copy=True)
+        self._stale = True
+
+    def _materialize(self):
+        if self.__dict__.get("_stale"):
+            self._stale = False
+            self._sync(self._pending_words)
+
+    def _sync(self, words=None):
+        from .state import unpack_state
         lv = self._b.level
-        s = self._b.snapshot()
-        self.t = int(s["t"][0])
-        self.completed_subtasks = [int(v) for v in s["completed"][0]]
-        self.goal_objects_count = [int(v) for v in s["goal_count"][0]]
+        self._stale = False
+        s = self._b.snapshot() if words is None else unpack_state(words, lv.num_agents, lv.num_items,
+                                                                  lv.num_subtasks)
+        self._v_t = int(s["t"][0])
+        self._v_completed_subtasks = [int(v) for v in s["completed"][0]]
+        self._v_goal_objects_count = [int(v) for v in s["goal_count"][0]]
         items, agents, order = s["items"][0], s["agents"][0], s["order"][0]
         objs = {}
         for g in order:
@@ -136,12 +165,12 @@ class OvercookedEnvironment:
             members = [i for i in range(lv.num_items) if items[i][3] == g]
             contents = [_Content(lv.items[i][0], int(items[i][2])) for i in members]
             objs[int(g)] = _Object(contents, (int(items[g][0]), int(items[g][1])), items[g][4] >= 0)
-        self.world.objects_in_order = [objs[int(g)] for g in order if g >= 0]
-        for a, ag in enumerate(self.sim_agents):
+        self._v_world.objects_in_order = [objs[int(g)] for g in order if g >= 0]
+        for a, ag in enumerate(self._v_sim_agents):
             ag.location = (int(agents[a][0]), int(agents[a][1]))
             ag.holding = objs.get(int(agents[a][2])) if agents[a][2] >= 0 else None
-        self._error = int(s["error"][0])
-        self.rep = self._render()
+        self._v__error = int(s["error"][0])
+        self._v_rep = self._render()
 
     def _render(self):
         """world.update_display + agents (overcooked_environment.py:442-446, world.py:38-48)."""
@@ -290,7 +319,8 @@ class OvercookedEnvironment:
         return img
 
     def display(self):
-        self.rep = self._render()
+        self._materialize()
+        self._v_rep = self._render()
 
     def get_agent_names(self):
         return [a.name for a in self.sim_agents]
@@ -518,6 +548,7 @@ def _make_multi_env_class():
                 lv.width, lv.height, lv.num_subtasks, self._b.C)
             self._layout = obs_layout(lv.num_subtasks, self._b.C)
             self._act = torch.zeros((4, 1), dtype=torch.int32, device=self._b.device)
+            self._act_host = torch.zeros((4, 1), dtype=torch.int32).pin_memory()
             self.multi_reset()
 
         @property
@@ -532,8 +563,11 @@ def _make_multi_env_class():
             return out
 
         def _obs_dicts(self, obs, ts):
-            o = obs.cpu().numpy()[:, :, 0].astype(np.int64)
-            t = ts.cpu().numpy()
+            """obs [2][F][1], ts [1]: device tensors or their host copies (BatchedOvercooked.fetch)."""
+            if isinstance(obs, torch.Tensor):
+                obs, ts = obs.cpu().numpy(), ts.cpu().numpy()
+            o = obs[:, :, 0].astype(np.int64)
+            t = ts
             ego_blind = bool(self._b.ego_config["BLIND"])
             out = []
             for v in range(2):
@@ -560,16 +594,20 @@ def _make_multi_env_class():
             return self._obs_dicts(obs, ts)[agent_idx]
 
         def multi_step(self, ego_action, alt_action):
-            self._act[:, 0] = torch.tensor([int(ego_action[0]), int(ego_action[1]),
-                                            int(alt_action[0]), int(alt_action[1])], dtype=torch.int32)
             for v in (ego_action[0], alt_action[0]):
                 if not 0 <= int(v) < 4:
                     raise IndexError("list index out of range")        # NAV_ACTIONS[idx] (:248)
-            obs, ts, rew, done = self._b.multi_step(self._act, auto_reset=False)
-            o0, o1 = self._obs_dicts(obs, ts)
-            r = float(rew.item())
-            self.base_env._sync()
-            return (o0, o1), (r, r), bool(done.item()), {}
+            # one pinned host->device copy in, one launch, ONE device->host copy out
+            h = self._act_host
+            h[0, 0], h[1, 0] = int(ego_action[0]), int(ego_action[1])
+            h[2, 0], h[3, 0] = int(alt_action[0]), int(alt_action[1])
+            self._act.copy_(h, non_blocking=True)
+            self._b.multi_step(self._act, auto_reset=False)
+            out = self._b.fetch()
+            o0, o1 = self._obs_dicts(out["obs"], out["timestep"])
+            r = float(out["shaped_reward"][0])
+            self.base_env._mark_stale(out["state"])     # the mirror is rebuilt only if somebody reads it
+            return (o0, o1), (r, r), bool(out["done"][0]), {}
 
         def multi_reset(self):
             self.base_env.reset()
