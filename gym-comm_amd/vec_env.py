@@ -162,30 +162,67 @@ class OvercookedVecEnv(_VecEnvBase):
     def _to_numpy(obs):
         return {k: v.cpu().numpy().astype(SPACE_DTYPE[k]) for k, v in obs.items()}
 
-    def _ego_obs_numpy(self):
-        """The ego viewer's 11 keys on the host.  The [F][n] rows are gathered by target dtype
-        (int64 / float32 / int8 as the declared spaces, overcooked_env.py:41-85), transposed and
-        cast on the GPU, and cross PCIe as three contiguous [n][k] blocks; the per-key arrays
-        are column views of those blocks (no host-side casts)."""
+    def _host_step(self, rew=None, done=None):
+        """Everything the numpy API returns for one step, in ONE device->host copy.  The ego
+        viewer's [F][n] rows are gathered by target dtype (int64 / float32 / int8 as the
+        declared spaces, overcooked_env.py:41-85), transposed and cast on the GPU; those
+        blocks, the float32 timestep, the float32 reward and the done flags are concatenated
+        as bytes (widest elements first, so every block stays aligned) and cross PCIe together;
+        the per-key arrays are column views of the host copy (no host-side casts)."""
         b = self._b
         if self._dtype_groups is None:
             groups = {}
             for k, (lo, hi) in b._layout.items():
                 groups.setdefault(SPACE_DTYPE[k], []).append((k, lo, hi))
             self._dtype_groups = []
-            for dt, keys in groups.items():
+            for dt in sorted(groups, key=lambda d: -np.dtype(d).itemsize):
+                keys = groups[dt]
                 rows = torch.tensor([r for _, lo, hi in keys for r in range(lo, hi)], device=b.device)
                 cols, c = {}, 0
                 for k, lo, hi in keys:
                     cols[k] = (c, c + hi - lo)
                     c += hi - lo
-                self._dtype_groups.append((getattr(torch, np.dtype(dt).name), rows, cols))
-        out = {"timestep": b.timestep.to(torch.float32).cpu().numpy().reshape(-1, 1)}
-        for tdt, rows, cols in self._dtype_groups:
-            block = b.obs[0].index_select(0, rows).T.to(tdt).contiguous().cpu().numpy()   # [n][k]
-            for k, (lo, hi) in cols.items():
-                out[k] = block[:, lo:hi]
-        return out
+                self._dtype_groups.append((np.dtype(dt), getattr(torch, np.dtype(dt).name), rows, cols, c))
+        n = self.num_envs
+        parts, plan = [], []            # device byte blocks; (name, numpy dtype, shape, cols)
+        for ndt, tdt, rows, cols, width in self._dtype_groups:
+            parts.append(b.obs[0].index_select(0, rows).T.to(tdt).contiguous())
+            plan.append(("obs", ndt, (n, width), cols))
+        f32 = [("timestep", b.timestep)] + ([("rew", rew)] if rew is not None else [])
+        for name, t in f32:
+            parts.append(t.to(torch.float32))
+            plan.append((name, np.dtype(np.float32), (n,), None))
+        if done is not None:
+            parts.append(done)
+            plan.append(("done", np.dtype(np.int32), (n,), None))
+        # order by element size, widest first (stable): offsets stay multiples of the element size
+        order = sorted(range(len(parts)), key=lambda i: -plan[i][1].itemsize)
+        # small batches are latency-bound (one copy instead of six: 268 -> 235 us at n = 4096);
+        # large ones are bandwidth-bound and the byte-wise concatenation only adds a pass
+        # (1.6 -> 2.4 ms at n = 131072), so there every block crosses on its own
+        single = n <= 16384
+        if single:
+            host = torch.cat([parts[i].reshape(-1).view(torch.uint8) for i in order]).cpu().numpy()
+        out, obs, off = {}, {}, 0
+        for i in order:
+            name, ndt, shape, cols = plan[i]
+            nb = int(np.prod(shape)) * ndt.itemsize
+            if single:
+                arr = host[off:off + nb].view(ndt).reshape(shape)
+            else:
+                arr = parts[i].cpu().numpy().reshape(shape)
+            off += nb
+            if name == "obs":
+                for k, (lo, hi) in cols.items():
+                    obs[k] = arr[:, lo:hi]
+            elif name == "timestep":
+                obs["timestep"] = arr.reshape(-1, 1)
+            else:
+                out[name] = arr
+        return obs, out.get("rew"), out.get("done")
+
+    def _ego_obs_numpy(self):
+        return self._host_step()[0]
 
     def reset(self):
         self.reset_tensors()
@@ -195,9 +232,9 @@ class OvercookedVecEnv(_VecEnvBase):
         self._pending = np.asarray(actions)
 
     def step_wait(self):
-        obs, rew, done = self.step_tensors(torch.from_numpy(self._pending.astype(np.int32)))
-        done_np = done.cpu().numpy().astype(bool)
-        rew_np = rew.to(torch.float32).cpu().numpy()
+        _, rew, done = self.step_tensors(torch.from_numpy(self._pending.astype(np.int32)))
+        obs_np, rew_np, done_i32 = self._host_step(rew, done)
+        done_np = done_i32.astype(bool)
         infos = self._infos                       # the same list every step (as DummyVecEnv's buf_infos)
         for i in self._dirty:
             infos[i] = {}
@@ -214,7 +251,7 @@ class OvercookedVecEnv(_VecEnvBase):
             m = done.bool()
             self.episode_returns[m] = 0
             self.episode_lengths[m] = 0
-        return self._ego_obs_numpy(), rew_np, done_np, list(infos)   # shallow copy: holders keep their dicts
+        return obs_np, rew_np, done_np, list(infos)   # shallow copy: holders keep their dicts
 
     def close(self):
         pass
