@@ -479,7 +479,7 @@ template <int A, int M>
 __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
                                          Env<A, M> &e, const int (&act_in)[A], int &reward, int &done,
                                          int &success, ShapeIn<(A < 2 ? A : 2)> &sin,
-                                         ShapeLoads<(A < 2 ? A : 2)> &sld OC_STAMP_PARAM) {
+                                         ShapeLoads<(A < 2 ? A : 2)> &sld, bool issue_shaping OC_STAMP_PARAM) {
   const int W = L.W, H = L.H;
   e.t = min(e.t + 1, 0xFFFF);  // :213 (16-bit field: saturates; max_num_timesteps <= 65535 is enforced)
 
@@ -673,7 +673,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   int ipb[M];
 #pragma unroll
   for (int i = 0; i < M; i++) ipb[i] = ipos(e.iw[i]);
-  shaping_issue<B, M>(L, dist, sin, ipb, sld);
+  if (issue_shaping) shaping_issue<B, M>(L, dist, sin, ipb, sld);   // uniform
   OC_STAMP(3);   // done/reward computed, distance loads issued
 }
 
@@ -950,7 +950,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
 #ifdef OC_STAMPS
     unsigned long long oc_tt[16];
 #endif
-    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
+    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld, true OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     Out(p.reward, p.n, 1, i).st(0, reward);
@@ -1120,7 +1120,15 @@ struct MultiArgs {
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
-template <int M, bool LDS, bool O8, bool WT>
+//
+// SPLIT: two waves per 64 envs (128-thread workgroups) for batches that leave most SIMDs idle
+// (n <= 16 384, see split_waves()).  Both waves load the state and
+// run the step up to done/reward redundantly -- that part is sequential anyway -- and then
+// share what follows: wave 0 stores done / state / viewer 0's observation / timestep and adds
+// the metrics, wave 1 finishes the reward shaping, stores the shaped reward and viewer 1's
+// observation.  One workgroup barrier keeps wave 0's state stores behind wave 1's state loads.
+// Not used with the in-kernel placement RNG (its per-env state is read-modify-write).
+template <int M, bool LDS, bool O8, bool WT, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
                                                     int32_t *const comm_, int64_t *const metrics_,
                                                     const int64_t n_, const int32_t block_,
@@ -1132,15 +1140,18 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   constexpr int A = 2;
   using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
-  const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
+  // n < 2^31 / (4 * rows): fits_buffer()
+  const int half = SPLIT ? (int)(threadIdx.x >> 6) : 0;   // which wave of the pair (wave-uniform)
+  const int i = SPLIT ? (int)blockIdx.x * 64 + (int)(threadIdx.x & 63) : (int)blockIdx.x * block_ + (int)threadIdx.x;
   const bool valid = i < (int)n_;
+  const bool first = !SPLIT || half == 0, second = !SPLIT || half == 1;
 #ifdef OC_STAMPS
   unsigned long long oc_tt[16];
   for (int k = 0; k < 16; k++) oc_tt[k] = 0;
 #endif
   OC_STAMP(0);
   const Tables tb = stage_tables<LDS>(p.tables, p.n16, p.quot_bytes);
-  MetricsSlot slot(metrics_, i);
+  MetricsSlot slot(first ? metrics_ : nullptr, i);
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
@@ -1157,8 +1168,10 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     // comm one-hots (:227-246)
     const int c0 = p.cfg.communication_on ? ego_cm : -1;
     const int c1 = (p.cfg.communication_on && !p.cfg.ego_led) ? alt_cm : -1;
-    cm.st(0, c0);
-    cm.st(1, c1);
+    if (first) {
+      cm.st(0, c0);
+      cm.st(1, c1);
+    }
     // NAV_ACTIONS lookup + CAN_MOVE gating + ego_agent_idx (:248-262)
     const int em = (p.cfg.can_move_mask & 1) ? (ego_mv & 3) : OC_ACT_NOOP;
     const int am = (p.cfg.can_move_mask & 2) ? (alt_mv & 3) : OC_ACT_NOOP;
@@ -1168,13 +1181,17 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     const int err_before = e.err;
     ShapeIn<2> sin;
     ShapeLoads<2> sld;
-    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
+    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld, second OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
-    Out(p.done, p.n, 1, i).st(0, done);
+    // both waves of a pair cover the same envs, so both reach this barrier with the same lanes
+    if (SPLIT) __syncthreads();   // wave 1 holds the old state in registers; wave 0 may overwrite it
+    if (first) {
+      Out(p.done, p.n, 1, i).st(0, done);
 #ifndef OC_STAMPS
-    if (p.sparse != nullptr) Out(p.sparse, p.n, 1, i).st(0, reward);
+      if (p.sparse != nullptr) Out(p.sparse, p.n, 1, i).st(0, reward);
 #endif
+    }
     if (done && p.auto_reset) {
 #pragma unroll
       for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
@@ -1183,25 +1200,30 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     } else {
       pack<A, M>(e, w);
     }
+    if (first) {
 #pragma unroll
-    for (int r = 0; r < WS; r++) st.st(r, w[r]);
+      for (int r = 0; r < WS; r++) st.st(r, w[r]);
+    }
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
     const Out ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
 #pragma unroll
     for (int v = 0; v < 2; v++)
-      env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
-                        v * F);
-    Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
+      if (!SPLIT || half == v)   // uniform
+        env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1,
+                          ob, v * F);
+    if (first) Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
     OC_STAMP(4);   // state and observation stores issued
     // ... and they drain while the path distances arrive and the shaping is summed
-    double s0, s1;
-    shaping_finish<2>(L, tb.quot, sin, sld, s0, s1 OC_STAMP_PASS);
-    Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
+    if (second) {
+      double s0, s1;
+      shaping_finish<2>(L, tb.quot, sin, sld, s0, s1 OC_STAMP_PASS);
+      Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
+    }
   }
   OC_STAMP(7);   // every store issued
-  slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
+  slot.add(metrics_ != nullptr && first, valid, done, success, reward, comp, err);
   OC_STAMP(8);
 #ifdef OC_STAMPS
   // the sparse-reward pointer doubles as the debug buffer in this build: int64 [waves][16]
@@ -1248,6 +1270,24 @@ template <typename K>
 int launch_st(K kernel, const StepArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
   return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.metrics, a.n,
                   (int32_t)block_size_for(n), a);
+}
+// the SPLIT variant: 128-thread workgroups, 64 envs each
+template <typename K>
+int launch_ms_split(K kernel, const MultiArgs &a, int64_t n, void *stream) {
+  if (n == 0) return OC_OK;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, (hipStream_t)stream, a.state,
+                     a.actions, a.comm, a.metrics, a.n, (int32_t)64, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "kernel launch");
+  return OC_OK;
+}
+bool split_waves(int64_t n) {
+  // two waves per 64 envs while that leaves at most half the 1024 SIMDs busy.  MI355X,
+  // tomato-2: 3.79 -> 3.67 us at 4 096 envs, 4.54 -> 4.02 us at 8 192, 4.62 -> 4.20 us at
+  // 16 384; a wash at 32 768 (5.01 -> 4.90 us, salad-2 5.13 -> 5.18 us).
+  // OC_SPLIT=0/1 overrides (tuning / tests)
+  static const int forced = getenv("OC_SPLIT") ? atoi(getenv("OC_SPLIT")) : -1;
+  return forced >= 0 ? forced == 1 : n <= 16384;
 }
 template <typename K>
 int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
@@ -1631,6 +1671,12 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
 #define OC_MS(MM)                                                                     \
   do {                                                                                \
     if (in_lds && !o8) return launch_ms(k_multi_step<MM, true, false, false>, a, n, stream, lds);      \
+    if (split_waves(n) && rng == nullptr) {                                                            \
+      if (o8) return wt ? launch_ms_split(k_multi_step<MM, false, true, true, true>, a, n, stream)     \
+                        : launch_ms_split(k_multi_step<MM, false, true, false, true>, a, n, stream);   \
+      return wt ? launch_ms_split(k_multi_step<MM, false, false, true, true>, a, n, stream)            \
+                : launch_ms_split(k_multi_step<MM, false, false, false, true>, a, n, stream);          \
+    }                                                                                                  \
     if (o8) return wt ? launch_ms(k_multi_step<MM, false, true, true>, a, n, stream, 0)                \
                       : launch_ms(k_multi_step<MM, false, true, false>, a, n, stream, 0);              \
     return wt ? launch_ms(k_multi_step<MM, false, false, true>, a, n, stream, 0)                       \
