@@ -927,7 +927,8 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
   const LevelHdr &L = OC_HDR(p);
   const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
   const bool valid = i < (int)n_;
-  const Tables tb = stage_tables<LDS>(p.tables, p.n16, p.quot_bytes);
+  Tables tb;   // (global variant: formed after the state loads are issued, see k_multi_step)
+  if constexpr (LDS) tb = stage_tables<true>(p.tables, p.n16, p.quot_bytes);
   MetricsSlot slot(metrics_, i);
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
@@ -941,6 +942,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
     int act[A];
 #pragma unroll
     for (int a = 0; a < A; a++) act[a] = ac.ld(a);
+    if constexpr (!LDS) tb = stage_tables<false>(p.tables, p.n16, p.quot_bytes);
     Env<A, M> e;
     unpack<A, M>(e, w);
     const int err_before = e.err;
@@ -1150,7 +1152,11 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   for (int k = 0; k < 16; k++) oc_tt[k] = 0;
 #endif
   OC_STAMP(0);
-  const Tables tb = stage_tables<LDS>(p.tables, p.n16, p.quot_bytes);
+  // LDS variant: staged first (its loads overlap the state loads).  Global variant: the table
+  // base pointers are formed AFTER the state loads are issued -- formed first, their scalar
+  // kernarg load was waited for before a single vector load had left.
+  Tables tb;
+  if constexpr (LDS) tb = stage_tables<true>(p.tables, p.n16, p.quot_bytes);
   MetricsSlot slot(first ? metrics_ : nullptr, i);
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
@@ -1162,6 +1168,11 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
 #pragma unroll
     for (int r = 0; r < WS; r++) w[r] = st.ld(r);
     const int ego_mv = ac.ld(0), ego_cm = ac.ld(1), alt_mv = ac.ld(2), alt_cm = ac.ld(3);
+    if constexpr (!LDS) tb = stage_tables<false>(p.tables, p.n16, p.quot_bytes);
+    // the output pointers are needed hundreds of instructions from here, where the compiler
+    // would place their scalar loads -- and a wait on them -- in the middle of the step; fetch
+    // them now, under the wait for the state that has to be served anyway
+    asm volatile("" ::"s"(p.obs), "s"(p.timestep), "s"(p.reward), "s"(p.done), "s"(p.sparse), "s"(p.auto_reset));
     Env<A, M> e;
     unpack<A, M>(e, w);
     OC_STAMP(1);   // state + actions arrived
