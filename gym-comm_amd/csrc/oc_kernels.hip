@@ -1172,7 +1172,8 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     // the output pointers are needed hundreds of instructions from here, where the compiler
     // would place their scalar loads -- and a wait on them -- in the middle of the step; fetch
     // them now, under the wait for the state that has to be served anyway
-    asm volatile("" ::"s"(p.obs), "s"(p.timestep), "s"(p.reward), "s"(p.done), "s"(p.sparse), "s"(p.auto_reset));
+    asm volatile("" ::"s"(tb.dist), "s"(tb.quot), "s"(p.obs), "s"(p.timestep), "s"(p.reward), "s"(p.done),
+                 "s"(p.sparse), "s"(p.auto_reset));
     Env<A, M> e;
     unpack<A, M>(e, w);
     OC_STAMP(1);   // state + actions arrived
