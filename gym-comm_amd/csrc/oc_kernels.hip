@@ -291,10 +291,10 @@ constexpr int AUX_WT = 16;      // sc1
 // cell of its (all-chopped) object if one exists.  The int/int divisions of the reference
 // are entries of the quotient table k / MAX_PATH; sums run left to right in fp64.
 //
-// Split in two so the kernels can put their stores in between: shaping_issue() forms the
-// addresses and issues every path-distance load; the observation / state stores then keep
-// the memory pipeline busy while the loads are in flight; shaping_finish() consumes the
-// distances, looks the quotients up and does the fp64 sums.
+// Split in three so the kernels can order their memory operations: shaping_issue() forms the
+// addresses and issues every path-distance load; shaping_lookup() consumes the distances and
+// issues the quotient loads -- still ahead of the observation stores, because vmcnt retires
+// loads and stores in issue order; shaping_sum() does the fp64 adds after the stores.
 template <int B>
 struct ShapeIn {   // what shaping_finish() still needs of the pre-reset env
   int ap[B];
@@ -369,10 +369,22 @@ __device__ __forceinline__ void shaping_issue(const LevelHdr &L, const uint8_t *
   }
 }
 
+// quotient values in flight between shaping_lookup() and shaping_sum()
 template <int B>
-__device__ __forceinline__ void shaping_finish(const LevelHdr &L, const double *__restrict__ quot,
-                                               const ShapeIn<B> &in, const ShapeLoads<B> &ld, double &s0,
-                                               double &s1 OC_STAMP_PARAM) {
+struct ShapeQ {
+  double q_chop[B], q_pair, q_del[MAX_DELS][B];
+  int nchop, npairs;
+  bool del_direct[MAX_DELS][B];
+};
+
+// second third: consume the path distances (integer min / select logic) and issue the
+// quotient lookups.  Called BEFORE the observation stores: vmcnt counts loads and stores
+// together in issue order, so a quotient load issued after ~60 stores could only be consumed
+// once every one of those stores had completed (1 900 cycles at 131 072 envs).
+template <int B>
+__device__ __forceinline__ void shaping_lookup(const LevelHdr &L, const double *__restrict__ quot,
+                                               const ShapeIn<B> &in, const ShapeLoads<B> &ld,
+                                               ShapeQ<B> &q OC_STAMP_PARAM) {
   const int MAXP = L.max_path;
   const int completed = in.completed;
   int d_tile[B];  // min over Delivery tiles of path distance + manhattan (:382-388)
@@ -421,45 +433,50 @@ __device__ __forceinline__ void shaping_finish(const LevelHdr &L, const double *
   for (int b = 0; b < B; b++) kq_chop[b] = nchop ? (mind[b] + MAXP) + (nchop - 1) * 2 * MAXP : 0;
   kq_pair = nchop ? npairs * MAXP : (npairs ? minpair + (npairs - 1) * MAXP : 0);
   int kq_del[MAX_DELS][B];
-  bool del_direct[MAX_DELS][B];
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++)
 #pragma unroll
     for (int b = 0; b < B; b++) {
       kq_del[k][b] = 0;
-      del_direct[k][b] = false;
+      q.del_direct[k][b] = false;
       if (k < (int)L.ndel) {
         const int d = ld.d_del[k][b] + manhattan(in.ap[b], in.del_p[k]);
-        del_direct[k][b] = d == 0;                 // the agent holds it (:381)
+        q.del_direct[k][b] = d == 0;                 // the agent holds it (:381)
         kq_del[k][b] = d == 0 ? d_tile[b] : d;
       }
     }
   OC_STAMP(5);   // distances consumed
   const int qmax = (int)L.nquot - 1;
-  double q_chop[B], q_pair, q_del[MAX_DELS][B];
 #pragma unroll
-  for (int b = 0; b < B; b++) q_chop[b] = quot[(unsigned)min(kq_chop[b], qmax)];
-  q_pair = quot[(unsigned)min(kq_pair, qmax)];
+  for (int b = 0; b < B; b++) q.q_chop[b] = quot[(unsigned)min(kq_chop[b], qmax)];
+  q.q_pair = quot[(unsigned)min(kq_pair, qmax)];
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++)
 #pragma unroll
-    for (int b = 0; b < B; b++) q_del[k][b] = (k < (int)L.ndel) ? quot[(unsigned)min(kq_del[k][b], qmax)] : 0.0;
+    for (int b = 0; b < B; b++) q.q_del[k][b] = (k < (int)L.ndel) ? quot[(unsigned)min(kq_del[k][b], qmax)] : 0.0;
+  q.nchop = nchop;
+  q.npairs = npairs;
+}
 
+// last third: the fp64 sums in the reference's order
+template <int B>
+__device__ __forceinline__ void shaping_sum(const LevelHdr &L, const ShapeIn<B> &in, const ShapeQ<B> &q,
+                                            double &s0, double &s1 OC_STAMP_PARAM) {
   double tot[B];
 #pragma unroll
   for (int b = 0; b < B; b++) {
     // `tot = 0; tot += x` of the reference is x itself (the quotients are never -0.0), so the
     // first term is selected, not added to zero
-    tot[b] = nchop ? q_chop[b] : 0.0;
-    tot[b] = npairs ? tot[b] + q_pair : tot[b];
+    tot[b] = q.nchop ? q.q_chop[b] : 0.0;
+    tot[b] = q.npairs ? tot[b] + q.q_pair : tot[b];
   }
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++)
     if (k < (int)L.ndel) {  // uniform; Deliver term in subtask order (:370-395)
-      const bool open = !((completed >> L.del_bit[k]) & 1);
+      const bool open = !((in.completed >> L.del_bit[k]) & 1);
 #pragma unroll
       for (int b = 0; b < B; b++) {
-        const double add = !in.del_has[k] ? 2.0 : (del_direct[k][b] ? q_del[k][b] : q_del[k][b] + 1.0);
+        const double add = !in.del_has[k] ? 2.0 : (q.del_direct[k][b] ? q.q_del[k][b] : q.q_del[k][b] + 1.0);
         tot[b] = open ? tot[b] + add : tot[b];
       }
     }
@@ -758,16 +775,16 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // lane (every field wide enough for a sum over 64 lanes), both words are summed across the
 // wave with DPP adds, the totals are read from lane 63 into SGPRs, split by scalar bit-field
 // extracts and written back into lanes 0..5, and lane k adds counter k to the wave's OWN
-// 64-byte slot of the metrics tensor (one load issued at kernel start, one store; no
-// atomics).  Must be called with all 64 lanes active.
+// 64-byte slot of the metrics tensor (one no-return atomic per lane, no two waves share a
+// slot).  Must be called with all 64 lanes active.
 struct MetricsSlot {
-  int64_t *p;
-  int64_t old;
-  // thread_index: global thread id; one slot per wave
+  unsigned long long *p;
+  // thread_index: global thread id; one slot per 64 envs
   __device__ __forceinline__ MetricsSlot(int64_t *metrics, int64_t thread_index) {
     const int lane = threadIdx.x & 63;
-    p = (metrics != nullptr && lane < 6) ? metrics + (thread_index >> 6) * OC_MET_COUNT + lane : nullptr;
-    old = p ? *p : 0;
+    p = (metrics != nullptr && lane < 6)
+            ? (unsigned long long *)metrics + (thread_index >> 6) * OC_MET_COUNT + lane
+            : nullptr;
   }
   __device__ __forceinline__ void add(bool has_metrics, bool valid, int done, int success, int reward,
                                       int completed_bits, bool err) {
@@ -790,7 +807,11 @@ struct MetricsSlot {
     const unsigned off = (OFF >> k5) & 31, wid = (WID >> k5) & 31;
     const unsigned src = (lane == OC_MET_REWARD_SUM || lane == OC_MET_COMPLETED_SUM) ? ta : tb;
     const int v = (int)((src >> off) & ((1u << wid) - 1u));
-    if (p) *p = old + v;
+    // Fire-and-forget atomic add by lanes 0..5, each to its own word of the wave's OWN slot (no
+    // contention).  A load at kernel start + a plain store here had to be consumed behind the
+    // 60+ stores of the step: vmcnt retires in issue order, so the wave ended on an
+    // s_waitcnt vmcnt(0) -- a wait for every store it had issued.
+    if (p) __hip_atomic_fetch_add(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
 
@@ -955,6 +976,8 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
     env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld, true OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
+    ShapeQ<B> sq;
+    shaping_lookup<B>(L, tb.quot, sin, sld, sq OC_STAMP_PASS);   // quotient loads ahead of the stores
     Out(p.reward, p.n, 1, i).st(0, reward);
     Out(p.done, p.n, 1, i).st(0, done);
     if (done && p.auto_reset) {
@@ -966,9 +989,8 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
     }
 #pragma unroll
     for (int r = 0; r < WS; r++) st.st(r, w[r]);
-    // the stores above drain while the path distances arrive
     double s0, s1;
-    shaping_finish<B>(L, tb.quot, sin, sld, s0, s1 OC_STAMP_PASS);
+    shaping_sum<B>(L, sin, sq, s0, s1 OC_STAMP_PASS);
     const Out sh(p.shaping, p.n, 2, i, 8);
     sh.st_f64(0, s0);
     sh.st_f64(1, s1);
@@ -1216,6 +1238,8 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
 #pragma unroll
       for (int r = 0; r < WS; r++) st.st(r, w[r]);
     }
+    ShapeQ<2> sq;
+    if (second) shaping_lookup<2>(L, tb.quot, sin, sld, sq OC_STAMP_PASS);   // quotient loads ahead of the obs stores
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
@@ -1227,10 +1251,10 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
                           ob, v * F);
     if (first) Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
     OC_STAMP(4);   // state and observation stores issued
-    // ... and they drain while the path distances arrive and the shaping is summed
+    // ... and they drain while the shaping is summed
     if (second) {
       double s0, s1;
-      shaping_finish<2>(L, tb.quot, sin, sld, s0, s1 OC_STAMP_PASS);
+      shaping_sum<2>(L, sin, sq, s0, s1 OC_STAMP_PASS);
       Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
     }
   }
