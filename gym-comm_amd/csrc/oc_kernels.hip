@@ -496,7 +496,7 @@ template <int A, int M>
 __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
                                          Env<A, M> &e, const int (&act_in)[A], int &reward, int &done,
                                          int &success, ShapeIn<(A < 2 ? A : 2)> &sin,
-                                         ShapeLoads<(A < 2 ? A : 2)> &sld, bool issue_shaping OC_STAMP_PARAM) {
+                                         ShapeLoads<(A < 2 ? A : 2)> &sld OC_STAMP_PARAM) {
   const int W = L.W, H = L.H;
   e.t = min(e.t + 1, 0xFFFF);  // :213 (16-bit field: saturates; max_num_timesteps <= 65535 is enforced)
 
@@ -690,7 +690,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   int ipb[M];
 #pragma unroll
   for (int i = 0; i < M; i++) ipb[i] = ipos(e.iw[i]);
-  if (issue_shaping) shaping_issue<B, M>(L, dist, sin, ipb, sld);   // uniform
+  shaping_issue<B, M>(L, dist, sin, ipb, sld);
   OC_STAMP(3);   // done/reward computed, distance loads issued
 }
 
@@ -973,7 +973,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
 #ifdef OC_STAMPS
     unsigned long long oc_tt[16];
 #endif
-    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld, true OC_STAMP_PASS);
+    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     ShapeQ<B> sq;
@@ -1144,15 +1144,7 @@ struct MultiArgs {
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
-//
-// SPLIT: two waves per 64 envs (128-thread workgroups) for batches that leave most SIMDs idle
-// (n <= 16 384, see split_waves()).  Both waves load the state and
-// run the step up to done/reward redundantly -- that part is sequential anyway -- and then
-// share what follows: wave 0 stores done / state / viewer 0's observation / timestep and adds
-// the metrics, wave 1 finishes the reward shaping, stores the shaped reward and viewer 1's
-// observation.  One workgroup barrier keeps wave 0's state stores behind wave 1's state loads.
-// Not used with the in-kernel placement RNG (its per-env state is read-modify-write).
-template <int M, bool LDS, bool O8, bool WT, bool SPLIT = false>
+template <int M, bool LDS, bool O8, bool WT>
 __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
                                                     int32_t *const comm_, int64_t *const metrics_,
                                                     const int64_t n_, const int32_t block_,
@@ -1164,11 +1156,8 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   constexpr int A = 2;
   using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
-  // n < 2^31 / (4 * rows): fits_buffer()
-  const int half = SPLIT ? (int)(threadIdx.x >> 6) : 0;   // which wave of the pair (wave-uniform)
-  const int i = SPLIT ? (int)blockIdx.x * 64 + (int)(threadIdx.x & 63) : (int)blockIdx.x * block_ + (int)threadIdx.x;
+  const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
   const bool valid = i < (int)n_;
-  const bool first = !SPLIT || half == 0, second = !SPLIT || half == 1;
 #ifdef OC_STAMPS
   unsigned long long oc_tt[16];
   for (int k = 0; k < 16; k++) oc_tt[k] = 0;
@@ -1179,7 +1168,7 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   // kernarg load was waited for before a single vector load had left.
   Tables tb;
   if constexpr (LDS) tb = stage_tables<true>(p.tables, p.n16, p.quot_bytes);
-  MetricsSlot slot(first ? metrics_ : nullptr, i);
+  MetricsSlot slot(metrics_, i);
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
@@ -1202,10 +1191,8 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     // comm one-hots (:227-246)
     const int c0 = p.cfg.communication_on ? ego_cm : -1;
     const int c1 = (p.cfg.communication_on && !p.cfg.ego_led) ? alt_cm : -1;
-    if (first) {
-      cm.st(0, c0);
-      cm.st(1, c1);
-    }
+    cm.st(0, c0);
+    cm.st(1, c1);
     // NAV_ACTIONS lookup + CAN_MOVE gating + ego_agent_idx (:248-262)
     const int em = (p.cfg.can_move_mask & 1) ? (ego_mv & 3) : OC_ACT_NOOP;
     const int am = (p.cfg.can_move_mask & 2) ? (alt_mv & 3) : OC_ACT_NOOP;
@@ -1215,17 +1202,13 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     const int err_before = e.err;
     ShapeIn<2> sin;
     ShapeLoads<2> sld;
-    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld, second OC_STAMP_PASS);
+    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
-    // both waves of a pair cover the same envs, so both reach this barrier with the same lanes
-    if (SPLIT) __syncthreads();   // wave 1 holds the old state in registers; wave 0 may overwrite it
-    if (first) {
-      Out(p.done, p.n, 1, i).st(0, done);
+    Out(p.done, p.n, 1, i).st(0, done);
 #ifndef OC_STAMPS
-      if (p.sparse != nullptr) Out(p.sparse, p.n, 1, i).st(0, reward);
+    if (p.sparse != nullptr) Out(p.sparse, p.n, 1, i).st(0, reward);
 #endif
-    }
     if (done && p.auto_reset) {
 #pragma unroll
       for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
@@ -1234,32 +1217,27 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     } else {
       pack<A, M>(e, w);
     }
-    if (first) {
 #pragma unroll
-      for (int r = 0; r < WS; r++) st.st(r, w[r]);
-    }
+    for (int r = 0; r < WS; r++) st.st(r, w[r]);
     ShapeQ<2> sq;
-    if (second) shaping_lookup<2>(L, tb.quot, sin, sld, sq OC_STAMP_PASS);   // quotient loads ahead of the obs stores
+    shaping_lookup<2>(L, tb.quot, sin, sld, sq OC_STAMP_PASS);   // quotient loads ahead of the obs stores
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
     const Out ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
 #pragma unroll
     for (int v = 0; v < 2; v++)
-      if (!SPLIT || half == v)   // uniform
-        env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1,
-                          ob, v * F);
-    if (first) Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
+      env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
+                        v * F);
+    Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
     OC_STAMP(4);   // state and observation stores issued
     // ... and they drain while the shaping is summed
-    if (second) {
-      double s0, s1;
-      shaping_sum<2>(L, sin, sq, s0, s1 OC_STAMP_PASS);
-      Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
-    }
+    double s0, s1;
+    shaping_sum<2>(L, sin, sq, s0, s1 OC_STAMP_PASS);
+    Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
   }
   OC_STAMP(7);   // every store issued
-  slot.add(metrics_ != nullptr && first, valid, done, success, reward, comp, err);
+  slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
   OC_STAMP(8);
 #ifdef OC_STAMPS
   // the sparse-reward pointer doubles as the debug buffer in this build: int64 [waves][16]
@@ -1273,14 +1251,13 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-int block_size_for(int64_t n) {
-  // One wave per workgroup spreads a batch over the most CUs and measured fastest up to
-  // 262 144 envs (MI355X sweeps, profiles/r01_v3_block_lds_sweep.txt and
-  // profiles/r01_v5_wt_block_sweep.txt); two waves per workgroup from 524 288 envs on.
-  // OC_BLOCK overrides (tuning / tests).
+int block_size_for(int64_t) {
+  // One wave per workgroup spreads a batch over the most CUs and measured fastest at every
+  // batch size from 4 096 to 524 288 envs (MI355X sweeps, profiles/r01_v3_block_lds_sweep.txt,
+  // r01_v11_geometry_sweep.txt).  OC_BLOCK overrides (tuning / tests).
   static const int forced = getenv("OC_BLOCK") ? atoi(getenv("OC_BLOCK")) : 0;
   if (forced == 64 || forced == 128 || forced == 256) return forced;
-  return n >= 8 * 256 * 256 ? 128 : 64;
+  return 64;
 }
 
 // rows are addressed with 32-bit byte offsets through a buffer descriptor
@@ -1306,24 +1283,6 @@ template <typename K>
 int launch_st(K kernel, const StepArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
   return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.metrics, a.n,
                   (int32_t)block_size_for(n), a);
-}
-// the SPLIT variant: 128-thread workgroups, 64 envs each
-template <typename K>
-int launch_ms_split(K kernel, const MultiArgs &a, int64_t n, void *stream) {
-  if (n == 0) return OC_OK;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, (hipStream_t)stream, a.state,
-                     a.actions, a.comm, a.metrics, a.n, (int32_t)64, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail_hip(e, "kernel launch");
-  return OC_OK;
-}
-bool split_waves(int64_t n) {
-  // two waves per 64 envs while that leaves at most half the 1024 SIMDs busy.  MI355X,
-  // tomato-2: 3.79 -> 3.67 us at 4 096 envs, 4.54 -> 4.02 us at 8 192, 4.62 -> 4.20 us at
-  // 16 384; a wash at 32 768 (5.01 -> 4.90 us, salad-2 5.13 -> 5.18 us).
-  // OC_SPLIT=0/1 overrides (tuning / tests)
-  static const int forced = getenv("OC_SPLIT") ? atoi(getenv("OC_SPLIT")) : -1;
-  return forced >= 0 ? forced == 1 : n <= 16384;
 }
 template <typename K>
 int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
@@ -1707,12 +1666,6 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
 #define OC_MS(MM)                                                                     \
   do {                                                                                \
     if (in_lds && !o8) return launch_ms(k_multi_step<MM, true, false, false>, a, n, stream, lds);      \
-    if (split_waves(n) && rng == nullptr) {                                                            \
-      if (o8) return wt ? launch_ms_split(k_multi_step<MM, false, true, true, true>, a, n, stream)     \
-                        : launch_ms_split(k_multi_step<MM, false, true, false, true>, a, n, stream);   \
-      return wt ? launch_ms_split(k_multi_step<MM, false, false, true, true>, a, n, stream)            \
-                : launch_ms_split(k_multi_step<MM, false, false, false, true>, a, n, stream);          \
-    }                                                                                                  \
     if (o8) return wt ? launch_ms(k_multi_step<MM, false, true, true>, a, n, stream, 0)                \
                       : launch_ms(k_multi_step<MM, false, true, false>, a, n, stream, 0);              \
     return wt ? launch_ms(k_multi_step<MM, false, false, true>, a, n, stream, 0)                       \

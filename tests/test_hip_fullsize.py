@@ -208,13 +208,13 @@ def test_store_policy_variants_in_subprocess(wt):
     """The launcher picks default-policy stores below 8192 envs and write-through (sc1)
     stores from there on; OC_WRITE_THROUGH forces one of them per process.  Both variants
     of the fused kernel (int32 and int8 observation rows) against the oracle at a size where
-    the forced variant is NOT the default one (wt=1 at n=1111); the same switch forces the
-    one-wave (OC_SPLIT=0, not the default below 32 768 envs) and two-wave forms of the fused kernel."""
+    the forced variant is NOT the default one (wt=1 at n=1111); wt=0 doubles as the check
+    that the override is harmless."""
     import os
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, OC_WRITE_THROUGH=wt, OC_SPLIT=wt)   # wt=0: one wave per 64 envs; wt=1: two
+    env = dict(os.environ, OC_WRITE_THROUGH=wt)
     out = subprocess.run([sys.executable, "-c", _WT_SNIPPET % (ROOT, os.path.join(ROOT, "tests"))],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "store-policy variant ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

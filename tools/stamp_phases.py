@@ -5,7 +5,6 @@ steps and prints the median cycle count of every phase.  GPU box only."""
 import os
 import sys
 
-os.environ["OC_SPLIT"] = "0"          # the stamps describe the one-wave-per-64-envs form
 os.environ["OC_HIP_EXTRA_FLAGS"] = (os.environ.get("OC_HIP_EXTRA_FLAGS", "") + " -DOC_STAMPS").strip()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
