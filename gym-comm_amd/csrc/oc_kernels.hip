@@ -291,8 +291,8 @@ constexpr int AUX_WT = 16;      // sc1
 // cell of its (all-chopped) object if one exists.  The int/int divisions of the reference
 // are entries of the quotient table k / MAX_PATH; sums run left to right in fp64.
 //
-// Split in three so the kernels can order their memory operations: shaping_issue() forms the
-// addresses and issues every path-distance load; shaping_lookup() consumes the distances and
+// Split so the kernels can order their memory operations: shaping_issue_pos/_del() form the
+// addresses and issue the path-distance loads; shaping_lookup() consumes the distances and
 // issues the quotient loads -- still ahead of the observation stores, because vmcnt retires
 // loads and stores in issue order; shaping_sum() does the fp64 adds after the stores.
 template <int B>
@@ -309,11 +309,13 @@ struct ShapeLoads {   // raw path distances, in flight until shaping_finish()
   int d_tile[OC_MAX_DELIV][B];
 };
 
+// The lookups that only need positions (Chop, pair and Delivery-tile terms): issued right after
+// interact(), a hundred instructions before the rest, so they are back when shaping_lookup()
+// wants them.  Table offsets are unsigned 24-bit products: full-rate v_mul_u32_u24 /
+// v_mad_u32_u24 and a 32-bit offset on a scalar base (no 64-bit address arithmetic per lookup).
 template <int B, int M>
-__device__ __forceinline__ void shaping_issue(const LevelHdr &L, const uint8_t *__restrict__ dist,
-                                              const ShapeIn<B> &in, const int (&ipos)[M], ShapeLoads<B> &ld) {
-  // table offsets are unsigned 24-bit products: full-rate v_mul_u32_u24 / v_mad_u32_u24 and a
-  // 32-bit offset on a scalar base (no 64-bit address arithmetic per lookup)
+__device__ __forceinline__ void shaping_issue_pos(const LevelHdr &L, const uint8_t *__restrict__ dist,
+                                                  const ShapeIn<B> &in, const int (&ipos)[M], ShapeLoads<B> &ld) {
   const unsigned nc = (unsigned)L.ncells;
   unsigned arow[B];
 #pragma unroll
@@ -348,16 +350,6 @@ __device__ __forceinline__ void shaping_issue(const LevelHdr &L, const uint8_t *
     }
   }
 #pragma unroll
-  for (int k = 0; k < MAX_DELS; k++) {
-#pragma unroll
-    for (int b = 0; b < B; b++) ld.d_del[k][b] = 0;
-    if (k < (int)L.ndel) {  // uniform
-      const unsigned mc = (unsigned)dense(L, in.del_p[k]);
-#pragma unroll
-      for (int b = 0; b < B; b++) ld.d_del[k][b] = dist[arow[b] + mc];
-    }
-  }
-#pragma unroll
   for (int k = 0; k < OC_MAX_DELIV; k++) {
 #pragma unroll
     for (int b = 0; b < B; b++) ld.d_tile[k][b] = 0;
@@ -365,6 +357,24 @@ __device__ __forceinline__ void shaping_issue(const LevelHdr &L, const uint8_t *
       const unsigned dc = (unsigned)dense(L, (int)L.deliv_pos[k]);
 #pragma unroll
       for (int b = 0; b < B; b++) ld.d_tile[k][b] = dist[arow[b] + dc];
+    }
+  }
+}
+
+// The Deliver-term lookups need the cell of each Deliver subtask's object (known after
+// done/reward).
+template <int B>
+__device__ __forceinline__ void shaping_issue_del(const LevelHdr &L, const uint8_t *__restrict__ dist,
+                                                  const ShapeIn<B> &in, ShapeLoads<B> &ld) {
+  const unsigned nc = (unsigned)L.ncells;
+#pragma unroll
+  for (int k = 0; k < MAX_DELS; k++) {
+#pragma unroll
+    for (int b = 0; b < B; b++) ld.d_del[k][b] = 0;
+    if (k < (int)L.ndel) {  // uniform
+      const unsigned mc = (unsigned)dense(L, in.del_p[k]);
+#pragma unroll
+      for (int b = 0; b < B; b++) ld.d_del[k][b] = dist[__umul24((unsigned)dense(L, in.ap[b]), nc) + mc];
     }
   }
 }
@@ -490,7 +500,7 @@ __device__ __forceinline__ void shaping_sum(const LevelHdr &L, const ShapeIn<B> 
 // (gym_cooking/envs/overcooked_environment.py:211-241)
 // ---------------------------------------------------------------------------
 // Everything up to done/reward, plus the address formation and the loads of the reward
-// shaping (shaping_issue); the caller stores what it has to store and then calls
+// shaping (shaping_issue_*); the caller stores what it has to store and then calls
 // shaping_finish(L, quot, sin, sld, ...).
 template <int A, int M>
 __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
@@ -630,6 +640,16 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     e.mctr += do_merge ? 1 : 0;
   }
 
+  // ---- calculate_reward_shaping (:272-397): the position-only distance lookups go out now ----
+  constexpr int B = A < 2 ? A : 2;
+#pragma unroll
+  for (int b = 0; b < B; b++) sin.ap[b] = e.ap[b];
+  {
+    int ipb[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) ipb[i] = ipos(e.iw[i]);
+    shaping_issue_pos<B, M>(L, dist, sin, ipb, sld);
+  }
   OC_STAMP(2);
   // ---- done (:243-270) and reward (:399-432) ---------------------------------
   // present / at_delivery: bit s set iff an Object with type-set s and every food chopped
@@ -668,10 +688,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   done = (timeout || all_delivered) ? 1 : 0;
   success = (!timeout && all_delivered) ? 1 : 0;
 
-  // ---- calculate_reward_shaping for sim agents 0 and 1 (:272-397): inputs + loads ----
-  constexpr int B = A < 2 ? A : 2;
-#pragma unroll
-  for (int b = 0; b < B; b++) sin.ap[b] = e.ap[b];
+  // ---- calculate_reward_shaping for sim agents 0 and 1 (:272-397): the rest of the inputs ----
   sin.completed = e.completed;
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++) {
@@ -687,10 +704,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
       }
     }
   }
-  int ipb[M];
-#pragma unroll
-  for (int i = 0; i < M; i++) ipb[i] = ipos(e.iw[i]);
-  shaping_issue<B, M>(L, dist, sin, ipb, sld);
+  shaping_issue_del<B>(L, dist, sin, sld);
   OC_STAMP(3);   // done/reward computed, distance loads issued
 }
 
