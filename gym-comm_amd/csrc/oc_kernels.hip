@@ -455,7 +455,6 @@ __device__ __forceinline__ void shaping_lookup(const LevelHdr &L, const double *
         kq_del[k][b] = d == 0 ? d_tile[b] : d;
       }
     }
-  OC_STAMP(5);   // distances consumed
   const int qmax = (int)L.nquot - 1;
 #pragma unroll
   for (int b = 0; b < B; b++) q.q_chop[b] = quot[(unsigned)min(kq_chop[b], qmax)];
@@ -466,6 +465,7 @@ __device__ __forceinline__ void shaping_lookup(const LevelHdr &L, const double *
     for (int b = 0; b < B; b++) q.q_del[k][b] = (k < (int)L.ndel) ? quot[(unsigned)min(kq_del[k][b], qmax)] : 0.0;
   q.nchop = nchop;
   q.npairs = npairs;
+  OC_STAMP(4);   // distances consumed, quotient loads issued
 }
 
 // last third: the fp64 sums in the reference's order
@@ -1244,7 +1244,7 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
       env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
                         v * F);
     Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
-    OC_STAMP(4);   // state and observation stores issued
+    OC_STAMP(5);   // observation stores issued
     // ... and they drain while the shaping is summed
     double s0, s1;
     shaping_sum<2>(L, sin, sq, s0, s1 OC_STAMP_PASS);

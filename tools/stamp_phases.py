@@ -12,9 +12,9 @@ import torch
 
 from gym_comm_amd.batched import BatchedOvercooked
 
-NAMES = ["start->state+actions in regs", "collisions+interact", "done/reward + issue distance loads",
-         "auto-reset, state store, obs x2 (stores issued)", "distances arrive + integer shaping",
-         "quotient loads + fp64 sums", "shaped reward stored", "metrics"]
+NAMES = ["start->state+actions in regs", "collisions+interact (+ position lookups issued)",
+         "done/reward (+ Deliver lookups issued)", "state stores, distances consumed, quotient loads issued",
+         "obs x2 (stores issued)", "quotients arrive + fp64 sums", "shaped reward stored", "metrics"]
 
 
 def main():
