@@ -85,8 +85,9 @@ typedef struct {
 } oc_wrap_cfg;
 
 /* metrics accumulated by the step kernels when `metrics` != NULL: a device tensor
- * int64 [oc_metrics_slots(n)][8] -- one 64-byte slot per wave (64 envs), added to without
- * atomics; the totals are the column sums.  Zero it to start a new rollout. */
+ * int64 [oc_metrics_slots(n)][8] -- one 64-byte slot per wave (64 envs); lanes 0..5 of the
+ * wave add their counter with a no-return atomic each (no two waves share a slot, so there
+ * is no contention); the totals are the column sums.  Zero it to start a new rollout. */
 enum {
   OC_MET_ENV_STEPS = 0,
   OC_MET_EPISODES = 1,      /* steps that returned done */
