@@ -155,8 +155,8 @@ def main():
     G = max(1, min(args.graph_steps, WINDOW))
     graph = None
     with torch.cuda.stream(stream):
-        for k in range(min(args.warmup, 64)):            # touch everything before capture
-            step_fn(acts[k % WINDOW])
+        for k in range(max(1, min(args.warmup, 64))):    # touch everything before capture (module load,
+            step_fn(acts[k % WINDOW])                    # first-launch work): at least once, also for --warmup 0
         stream.synchronize()
         tails = {}                                       # remainder length -> its own graph
 
