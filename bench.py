@@ -100,9 +100,24 @@ def cpu_baseline(level_blob, A, C, wrapper, seconds):
         el = time.perf_counter() - t0
         if el >= seconds:
             break
+    # the same loop on ONE host thread (SURVEY 8(d) asks for both), a quarter of the time budget
+    ora1 = oracle.OracleBatch(level_blob, n, threads=1)
+    steps1 = 0
+    t1 = time.perf_counter()
+    while True:
+        if wrapper:
+            ora1.multi_rollout(acts, comm, 2, 0, C, auto_reset=True)
+        else:
+            ora1.rollout(acts, auto_reset=True)
+        steps1 += chunk
+        el1 = time.perf_counter() - t1
+        if el1 >= seconds / 4:
+            break
     return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "value_1thread": n * steps1 / el1,
             "sample": "%d envs x %d steps of the same workload (%.1f s wall), C oracle "
-                      "(oracle/oc_oracle.c), %d threads" % (n, steps, el, cores)}
+                      "(oracle/oc_oracle.c), %d threads; 1 thread: %d steps in %.1f s"
+                      % (n, steps, el, cores, steps1, el1)}
 
 
 def main():
