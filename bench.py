@@ -53,8 +53,8 @@ def parse():
     p.add_argument("--graph-steps", type=int, default=WINDOW)
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N>1 on one GPU)")
     p.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    p.add_argument("--obs-dtype", default="int32", choices=["int32", "int8"],
-                   help="observation rows: int32 (SURVEY 8(d) accounting) or int8 (4x fewer bytes)")
+    p.add_argument("--obs-dtype", default="int32", choices=["int32", "int8", "float32"],
+                   help="observation rows: int32 (SURVEY 8(d) accounting), int8 (4x fewer bytes) or float32")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
@@ -152,7 +152,7 @@ def main():
     env = BatchedOvercooked(args.level, num_agents=args.agents, num_envs=n,
                             max_num_timesteps=args.T, num_communication=args.comm,
                             communication_on=True, fow_radius=2, device=dev, auto_reset=True,
-                            obs_dtype=torch.int8 if args.obs_dtype == "int8" else torch.int32)
+                            obs_dtype=getattr(torch, args.obs_dtype))
     lv = env.level
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     if wrapper:

@@ -76,8 +76,8 @@ class BatchedOvercooked:
         self.W_state = self._L.oc_state_words(h)
         self.F = self._L.oc_obs_rows(h, self.C)
         n = self.n
-        if obs_dtype not in (torch.int32, torch.int8):
-            raise ValueError("obs_dtype must be torch.int32 or torch.int8")
+        if obs_dtype not in (torch.int32, torch.int8, torch.float32):
+            raise ValueError("obs_dtype must be torch.int32, torch.int8 or torch.float32")
         # Every tensor a step reads or writes is a view of ONE device allocation (each view
         # 256-byte aligned): a host consumer fetches the whole step -- state, rewards, done,
         # observations -- with a single device->host copy (`fetch()`), instead of one per tensor.
@@ -99,7 +99,7 @@ class BatchedOvercooked:
         self._obs_cfg = _lib.ObsCfg(int(fow_radius),
                                     (1 if self.ego_config["BLIND"] else 0) |
                                     (2 if self.partner_config["BLIND"] else 0), self.C,
-                                    1 if obs_dtype == torch.int8 else 0)
+                                    {torch.int32: 0, torch.int8: 1, torch.float32: 2}[obs_dtype])
         self._wrap_cfg = _lib.WrapCfg(self._obs_cfg, int(bool(communication_on)), int(bool(ego_led)),
                                       int(ego_agent_idx),
                                       (1 if self.ego_config["CAN_MOVE"] else 0) |

@@ -710,7 +710,9 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
 
 // get_observation2 (gym_comm/envs/overcooked_env.py:105-159) for one viewer;
 // writes F = 22 + S + 2C rows with stride n.
-template <int A, int M, bool O8, typename OutRows>
+// OT = element type of the observation rows: 0 int32, 1 int8, 2 float32 (the same integers,
+// converted; what a policy network's first layer consumes as obs[v].T without a cast)
+template <int A, int M, int OT, typename OutRows>
 __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, int viewer, int radius,
                                         bool viewer_blind, bool ego_blind, int C, int comm0, int comm1,
                                         const OutRows &out, int row0) {
@@ -745,7 +747,12 @@ __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, i
     }
     loc[0] = px(e.ap[0]), loc[1] = py(e.ap[0]), loc[2] = px(e.ap[1]), loc[3] = py(e.ap[1]);
   }
-#define OUT(r_, v_) do { if (O8) out.st8((r_), (v_)); else out.st((r_), (v_)); } while (0)
+#define OUT(r_, v_)                                                              \
+  do {                                                                           \
+    if (OT == 1) out.st8((r_), (v_));                                            \
+    else if (OT == 2) out.st((r_), __builtin_bit_cast(int, (float)(v_)));        \
+    else out.st((r_), (v_));                                                     \
+  } while (0)
   int row = row0;
 #pragma unroll
   for (int ch = 0; ch < 4; ch++) OUT(row++, ddx[ch]);
@@ -1017,13 +1024,13 @@ struct ObsArgs {
   RunCfg R;
   const int32_t *state;
   const int32_t *comm;
-  void *obs;          // int32 or int8 rows (cfg.obs_int8)
+  void *obs;          // int32, int8 or float32 rows (cfg.obs_int8)
   double *timestep;
   int64_t n;
   oc_obs_cfg cfg;
 };
 
-template <int A, int M, bool O8, bool WT>
+template <int A, int M, int OT, bool WT>
 __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
   using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
@@ -1040,10 +1047,10 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
   const int F = 22 + L.S + 2 * C;
   const int c0 = p.comm[i], c1 = p.comm[p.n + i];
   const bool ego_blind = p.cfg.blind_mask & 1;
-  const Out ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
+  const Out ob(p.obs, p.n, 2 * F, i, OT == 1 ? 1 : 4);
 #pragma unroll
   for (int v = 0; v < 2; v++)
-    env_obs<A, M, O8>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
+    env_obs<A, M, OT>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
   Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));  // overcooked_env.py:146
 }
 
@@ -1144,7 +1151,7 @@ struct MultiArgs {
   int32_t *state;
   int32_t *comm;
   const int32_t *actions;
-  void *obs;          // int32 or int8 rows (cfg.obs.obs_int8)
+  void *obs;          // int32, int8 or float32 rows (cfg.obs.obs_int8)
   double *timestep;
   double *reward;
   int32_t *done;
@@ -1158,7 +1165,7 @@ struct MultiArgs {
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
-template <int M, bool LDS, bool O8, bool WT>
+template <int M, bool LDS, int OT, bool WT>
 __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
                                                     int32_t *const comm_, int64_t *const metrics_,
                                                     const int64_t n_, const int32_t block_,
@@ -1238,10 +1245,10 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
-    const Out ob(p.obs, p.n, 2 * F, i, O8 ? 1 : 4);
+    const Out ob(p.obs, p.n, 2 * F, i, OT == 1 ? 1 : 4);
 #pragma unroll
     for (int v = 0; v < 2; v++)
-      env_obs<A, M, O8>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
+      env_obs<A, M, OT>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
                         v * F);
     Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
     OC_STAMP(5);   // observation stores issued
@@ -1631,14 +1638,20 @@ int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, cons
   ObsArgs a{lv->hdr, lv->run, state, comm, obs, timestep, n, *cfg};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
   const bool wt = write_through(n);
-  if (cfg->obs_int8) {
-#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, true, true>, a, n, stream, 0) \
-                                : launch(k_obs<AA, MM, true, false>, a, n, stream, 0)
+  if (cfg->obs_int8 < 0 || cfg->obs_int8 > 2) return fail(OC_E_BADARG, "oc_obs: obs_int8 must be 0 (int32), 1 (int8) or 2 (float32)");
+  if (cfg->obs_int8 == 1) {
+#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, 1, true>, a, n, stream, 0) \
+                                : launch(k_obs<AA, MM, 1, false>, a, n, stream, 0)
+    OC_FOR_AM(OC_X)
+#undef OC_X
+  } else if (cfg->obs_int8 == 2) {
+#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, 2, true>, a, n, stream, 0) \
+                                : launch(k_obs<AA, MM, 2, false>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   } else {
-#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, false, true>, a, n, stream, 0) \
-                                : launch(k_obs<AA, MM, false, false>, a, n, stream, 0)
+#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, 0, true>, a, n, stream, 0) \
+                                : launch(k_obs<AA, MM, 0, false>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   }
@@ -1675,15 +1688,18 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
               reward, done, sparse, metrics, placement, rng, n, auto_reset, *cfg};
   const size_t lds = (size_t)lv->n16 * 16;
   const bool in_lds = tables_in_lds(n);
-  const bool o8 = cfg->obs.obs_int8 != 0;
+  const int ot = cfg->obs.obs_int8;   // 0 int32, 1 int8, 2 float32
+  if (ot < 0 || ot > 2) return fail(OC_E_BADARG, "oc_multi_step: obs_int8 must be 0 (int32), 1 (int8) or 2 (float32)");
   const bool wt = write_through(n);
 #define OC_MS(MM)                                                                     \
   do {                                                                                \
-    if (in_lds && !o8) return launch_ms(k_multi_step<MM, true, false, false>, a, n, stream, lds);      \
-    if (o8) return wt ? launch_ms(k_multi_step<MM, false, true, true>, a, n, stream, 0)                \
-                      : launch_ms(k_multi_step<MM, false, true, false>, a, n, stream, 0);              \
-    return wt ? launch_ms(k_multi_step<MM, false, false, true>, a, n, stream, 0)                       \
-              : launch_ms(k_multi_step<MM, false, false, false>, a, n, stream, 0);                     \
+    if (in_lds && ot == 0) return launch_ms(k_multi_step<MM, true, 0, false>, a, n, stream, lds);      \
+    if (ot == 1) return wt ? launch_ms(k_multi_step<MM, false, 1, true>, a, n, stream, 0)              \
+                           : launch_ms(k_multi_step<MM, false, 1, false>, a, n, stream, 0);            \
+    if (ot == 2) return wt ? launch_ms(k_multi_step<MM, false, 2, true>, a, n, stream, 0)              \
+                           : launch_ms(k_multi_step<MM, false, 2, false>, a, n, stream, 0);            \
+    return wt ? launch_ms(k_multi_step<MM, false, 0, true>, a, n, stream, 0)                           \
+              : launch_ms(k_multi_step<MM, false, 0, false>, a, n, stream, 0);                         \
   } while (0)
 #ifdef OC_SPECIALIZED
   OC_MS(OC_SPEC_HDR.M);

@@ -58,7 +58,7 @@ typedef struct oc_level oc_level_t; /* opaque; device-resident static tables */
  * utils/agent.py:258-314, utils/core.py:149-237). */
 
 /* ---- observation tensor ----------------------------------------------------
- * int32 (or int8, see oc_obs_cfg.obs_int8) [2][oc_obs_rows()][n]: viewer 0 then viewer 1; rows per viewer, in the key
+ * int32 (or int8 / float32, see oc_obs_cfg.obs_int8) [2][oc_obs_rows()][n]: viewer 0 then viewer 1; rows per viewer, in the key
  * order of OvercookedMultiEnv.get_observation2
  * (gym_comm/envs/overcooked_env.py:145-157) minus `timestep`:
  *   object_encodings_x[4] object_encodings_y[4] state_encodings[4] is_hidden[4]
@@ -71,9 +71,10 @@ typedef struct {
   int32_t fow_radius;   /* arglist.fow_radius */
   int32_t blind_mask;   /* bit0: ego_config["BLIND"], bit1: partner_config["BLIND"] */
   int32_t num_comm;     /* arglist.num_communication (C) */
-  int32_t obs_int8;     /* 0: observation rows are int32; 1: int8 (every value fits: the
-                           kernel then moves 4x fewer observation bytes: 10.9 -> 8.9 us per
-                           launch at 131072 envs, 1.22x) */
+  int32_t obs_int8;     /* element type of the observation rows: 0 int32; 1 int8 (every value
+                           fits: 4x fewer observation bytes, 8.1 -> 6.1 us per launch at 131072
+                           envs); 2 float32 (the same integers converted -- what a policy
+                           network's first layer takes as obs[v].T without a cast) */
 } oc_obs_cfg;
 
 typedef struct {

@@ -346,17 +346,20 @@ def test_hundred_comm_channels_like_the_reference_configs(oracle_lib):
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "step+obs"])
+@pytest.mark.parametrize("odt", [torch.int8, torch.float32], ids=["int8", "float32"])
 @pytest.mark.parametrize("name", ["wrap_salad_open_c5.npz", "wrap_tl_full_blind_allergic.npz",
                                   "rwrap_rsuperwide_c5.npz", "cwrap_conion_r2.npz"])
-def test_int8_observation_rows_match_reference_golden(name, fused):
-    """oc_obs_cfg.obs_int8: the same observations as int8 rows (4x fewer bytes)."""
+def test_int8_observation_rows_match_reference_golden(name, odt, fused):
+    """oc_obs_cfg.obs_int8 = 1 / 2: the same observations as int8 rows (4x fewer bytes) or as
+    float32 rows (what a policy network takes without a cast); every value is a small integer,
+    so both are exact."""
     path = os.path.join(os.path.dirname(BASE[0]), name)
     z, st = load_golden(path)
     lv = compile_for(st)
     n = 130
-    env = _wrap_env(st, lv, n, auto_reset=False, placement_mode="host", obs_dtype=torch.int8,
+    env = _wrap_env(st, lv, n, auto_reset=False, placement_mode="host", obs_dtype=odt,
                     specialize_level=(name in SPEC_GOLDEN))
-    assert env.obs.dtype == torch.int8
+    assert env.obs.dtype == odt
     if lv.random_placement:
         env.set_placement(_placement_tensor(lv, z["placements"][0], n))
         env.reset()
