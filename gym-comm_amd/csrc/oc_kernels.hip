@@ -296,13 +296,13 @@ constexpr int AUX_WT = 16;      // sc1
 // issues the quotient loads -- still ahead of the observation stores, because vmcnt retires
 // loads and stores in issue order; shaping_sum() does the fp64 adds after the stores.
 template <int B>
-struct ShapeIn {   // what shaping_finish() still needs of the pre-reset env
+struct ShapeIn {   // what shaping_lookup() / shaping_sum() still need of the pre-reset env
   int ap[B];
   int completed;
   int del_has[MAX_DELS], del_p[MAX_DELS];
 };
 template <int B>
-struct ShapeLoads {   // raw path distances, in flight until shaping_finish()
+struct ShapeLoads {   // raw path distances, in flight until shaping_lookup()
   int d_chop[3][B];
   int d_pair[MAX_PAIRLK];
   int d_del[MAX_DELS][B];
@@ -501,7 +501,7 @@ __device__ __forceinline__ void shaping_sum(const LevelHdr &L, const ShapeIn<B> 
 // ---------------------------------------------------------------------------
 // Everything up to done/reward, plus the address formation and the loads of the reward
 // shaping (shaping_issue_*); the caller stores what it has to store and then calls
-// shaping_finish(L, quot, sin, sld, ...).
+// shaping_lookup(L, quot, sin, sld, sq) and, after its stores, shaping_sum(L, sin, sq, ...).
 template <int A, int M>
 __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
                                          Env<A, M> &e, const int (&act_in)[A], int &reward, int &done,
@@ -843,8 +843,8 @@ struct MetricsSlot {
 // device buffer.  Two variants of every step kernel exist (template bool LDS):
 //   LDS = false  the tables are read straight from global memory (vector L1/L2): no
 //                staging pass, no barrier.  The default: fastest at every batch size with
-//                64- or 128-thread workgroups (n = 4096: 4.7 us vs 5.7 us per step;
-//                n = 131072: 11.1 us vs 12.7 us).
+//                64- or 128-thread workgroups (round-1 v3 sweep: n = 4096: 4.7 us vs
+//                5.7 us per step; n = 131072: 11.1 us vs 12.7 us).
 //   LDS = true   every workgroup copies them to LDS with 16-byte loads issued BEFORE the
 //                state loads, so both round trips overlap.  Only ahead with 256-thread
 //                workgroups (n = 131072: 12.1 us vs 13.3 us), which lose overall.
