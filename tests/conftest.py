@@ -46,4 +46,4 @@ def oracle_lib():
     from oracle import oracle
     oracle.build()
     return oracle
-collect_ignore = ["soak.py"]
+collect_ignore = ["soak.py", "soak_wrapper.py"]
