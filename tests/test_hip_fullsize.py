@@ -218,3 +218,40 @@ def test_store_policy_variants_in_subprocess(wt):
     out = subprocess.run([sys.executable, "-c", _WT_SNIPPET % (ROOT, os.path.join(ROOT, "tests"))],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "store-policy variant ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_largest_batch_one_call_can_address(oracle_lib):
+    """Maximum size: rows are addressed with 32-bit byte offsets, so one call takes at most
+    2^31 / (4 * rows) envs.  8 388 608 envs (1.95 GB of int32 observation rows, 268 MB of
+    state) is inside that bound for tomato-2: the first 256 envs against the oracle, every other
+    tile of 256 equal to the first; 9 300 000 envs is outside and must be refused before any launch."""
+    from gym_comm_amd import compiler
+    from gym_comm_amd._lib import OcError
+    from gym_comm_amd.batched import BatchedOvercooked
+    level, n, T, steps, C = "open-divider_tomato", 1 << 23, 30, 36, 2
+    lv = compiler.compile_level(level, 2, T)
+    rng = np.random.default_rng(99)
+    ora = oracle_lib.OracleBatch(lv.blob, N0, threads=4)
+    env = BatchedOvercooked(lv, num_envs=n, num_communication=C, auto_reset=True, track_metrics=True)
+    mv = scripted_then_random(rng, level, steps, 2, N0, nact=4)
+    cm = rng.integers(0, C, (steps, 2, N0)).astype(np.int32)
+    acts0 = np.stack([mv[:, 0], cm[:, 0], mv[:, 1], cm[:, 1]], axis=1).astype(np.int32)
+    comm = np.zeros((2, N0), np.int32)
+    reps = n // N0
+    for k in range(steps):
+        ctx = "n=%d step %d" % (n, k)
+        a = torch.from_numpy(acts0[k]).cuda().repeat(1, reps).contiguous()
+        o, t, r, d = env.multi_step(a)
+        oo, to, ro, do = ora.multi_step(acts0[k], comm, 2, 0, C, auto_reset=True)
+        assert np.array_equal(o[:, :, :N0].cpu().numpy(), oo), ctx
+        assert np.array_equal(bits(r[:N0].cpu().numpy()), bits(ro)), ctx
+        assert np.array_equal(d[:N0].cpu().numpy(), do), ctx
+        if k % 6 == 5 or k == steps - 1:          # the tile comparison reads 2 GB: not every step
+            assert _tiled_equal(o, N0) and _tiled_equal(env.state, N0), ctx
+            assert _tiled_equal(d, N0) and _tiled_equal(r.view(torch.int64), N0), ctx
+    assert env.read_metrics()["env_steps"] == n * steps
+    del env
+    torch.cuda.empty_cache()
+    with pytest.raises(OcError, match="too large"):
+        BatchedOvercooked(lv, num_envs=9_300_000, num_communication=C).multi_step(
+            torch.zeros((4, 9_300_000), dtype=torch.int32, device="cuda"))
