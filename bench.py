@@ -275,6 +275,10 @@ def main():
             "agent_steps_per_sec": value * lv.num_agents,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         # the same with the bytes the PMC counters saw instead of SURVEY's int32-per-
+                         # field accounting (the packed state moves fewer): what the memory system did
+                         "traffic_gbps": (traffic / launch_s / 1e9) if traffic else None,
+                         "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "kernel": "k_multi_step" if wrapper else "k_step",
                          "algorithmic_bytes_per_env_step": bytes_per,
                          "avg_launch_us_timed_region": launch_s * 1e6,
