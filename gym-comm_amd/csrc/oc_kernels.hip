@@ -40,7 +40,6 @@ namespace {
 constexpr int MAX_GOALS = 16;   // distinct goal type-sets (all 15 non-empty subsets of 4 types fit)
 constexpr int MAX_DELS = 4;     // Deliver subtasks
 constexpr int MAX_PAIRLK = 12;  // item-pair distance lookups of the shaping pair term
-constexpr int PLATE_BIT = 1 << OC_PLATE;
 
 // Uniform per-level data.  Generic build: passed by value in the kernel arguments
 // (scalar loads).  Specialised build (-DOC_SPECIALIZED, one .so per level, see
@@ -663,8 +662,9 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     const int w = e.iw[i];
     const bool rep = (w & IW_GRP) == (i << 9);
     // a lone fresh food is the only Object that is not all-chopped
-    const bool lone_fresh = (item_type(L, i) != OC_PLATE) & ((w & (IW_TSET | IW_CHOP)) == ((1 << item_type(L, i)) << 24));
-    rep_ok[i] = rep & !lone_fresh;
+    const bool lone_fresh =
+        (int)(item_type(L, i) != OC_PLATE) & (int)((w & (IW_TSET | IW_CHOP)) == ((1 << item_type(L, i)) << 24));
+    rep_ok[i] = (int)rep & (int)!lone_fresh;
     const int b = rep_ok[i] ? (1 << itset(w)) : 0;
     present |= b;
     at_delivery |= ipos(w) == d0 ? b : 0;
@@ -698,7 +698,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
 #pragma unroll
       for (int i = 0; i < M; i++) {
         // `&`, not `&&`: the short-circuit form became an exec-masked region per item
-        const bool ok = rep_ok[i] & ((e.iw[i] & IW_TSET) == ((int)L.del_tset[k] << 24));
+        const bool ok = (int)rep_ok[i] & (int)((e.iw[i] & IW_TSET) == ((int)L.del_tset[k] << 24));
         sin.del_has[k] |= ok;
         sin.del_p[k] = ok ? ipos(e.iw[i]) : sin.del_p[k];
       }
