@@ -76,6 +76,7 @@ struct RunCfg {
   int32_t T;          // arglist.max_num_timesteps (0 = no limit)
   uint32_t allergic;  // bit a: agent a is ALLERGIC
   double inv_T;       // 1.0 / T, correctly rounded on the host (0 when T == 0)
+  double inv_max_path;  // 1.0 / MAX_PATH, correctly rounded on the host
 };
 
 #ifdef OC_STAMPS
@@ -378,7 +379,7 @@ __device__ __forceinline__ void shaping_issue_del(const LevelHdr &L, const uint8
   }
 }
 
-// quotient values in flight between shaping_lookup() and shaping_sum()
+// quotient values between shaping_lookup() and shaping_sum()
 template <int B>
 struct ShapeQ {
   double q_chop[B], q_pair, q_del[MAX_DELS][B];
@@ -386,14 +387,23 @@ struct ShapeQ {
   bool del_direct[MAX_DELS][B];
 };
 
-// second third: consume the path distances (integer min / select logic) and issue the
-// quotient lookups.  Called BEFORE the observation stores: vmcnt counts loads and stores
-// together in issue order, so a quotient load issued after ~60 stores could only be consumed
-// once every one of those stores had completed (1 900 cycles at 131 072 envs).
+// second part: consume the path distances (integer min / select logic) and form the
+// quotients.  (Until round-1 v11 the quotients were table lookups, issued here -- ahead of the
+// observation stores, because vmcnt retires loads and stores in issue order.)
+// k / MAX_PATH as CPython computes it (int / int, correctly rounded fp64) by the two-FMA
+// construction of timestep_of(): exact for every 0 <= k <= 65535, 1 <= MAX_PATH <= 65535
+// (tools/div_check.c).  Replaces a table lookup -- five to seven global loads per env-step
+// that had to be ordered around the stores.
+__device__ __forceinline__ double quotient(int k, const LevelHdr &L, double inv_max_path) {
+  const double dk = (double)k;
+  const double q0 = dk * inv_max_path;
+  const double r = __builtin_fma(-(double)L.max_path, q0, dk);
+  return __builtin_fma(r, inv_max_path, q0);
+}
+
 template <int B>
-__device__ __forceinline__ void shaping_lookup(const LevelHdr &L, const double *__restrict__ quot,
-                                               const ShapeIn<B> &in, const ShapeLoads<B> &ld,
-                                               ShapeQ<B> &q OC_STAMP_PARAM) {
+__device__ __forceinline__ void shaping_lookup(const LevelHdr &L, double inv_max_path, const ShapeIn<B> &in,
+                                               const ShapeLoads<B> &ld, ShapeQ<B> &q OC_STAMP_PARAM) {
   const int MAXP = L.max_path;
   const int completed = in.completed;
   int d_tile[B];  // min over Delivery tiles of path distance + manhattan (:382-388)
@@ -454,17 +464,16 @@ __device__ __forceinline__ void shaping_lookup(const LevelHdr &L, const double *
         kq_del[k][b] = d == 0 ? d_tile[b] : d;
       }
     }
-  const int qmax = (int)L.nquot - 1;
 #pragma unroll
-  for (int b = 0; b < B; b++) q.q_chop[b] = quot[(unsigned)min(kq_chop[b], qmax)];
-  q.q_pair = quot[(unsigned)min(kq_pair, qmax)];
+  for (int b = 0; b < B; b++) q.q_chop[b] = quotient(kq_chop[b], L, inv_max_path);
+  q.q_pair = quotient(kq_pair, L, inv_max_path);
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++)
 #pragma unroll
-    for (int b = 0; b < B; b++) q.q_del[k][b] = (k < (int)L.ndel) ? quot[(unsigned)min(kq_del[k][b], qmax)] : 0.0;
+    for (int b = 0; b < B; b++) q.q_del[k][b] = (k < (int)L.ndel) ? quotient(kq_del[k][b], L, inv_max_path) : 0.0;
   q.nchop = nchop;
   q.npairs = npairs;
-  OC_STAMP(4);   // distances consumed, quotient loads issued
+  OC_STAMP(4);   // distances consumed, quotients formed
 }
 
 // last third: the fp64 sums in the reference's order
@@ -964,7 +973,10 @@ struct StepArgs {
 template <int A, int M, bool LDS, bool WT>
 __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32_t *const actions_,
                                               int64_t *const metrics_, const int64_t n_, const int32_t block_,
+                                              const void *const tables_, const double inv_max_path_,
                                               const StepArgs p) {
+  // (tables_ / inv_max_path_ too: this kernel runs at the SGPR limit with 3-4 agents, and the
+  // compiler otherwise loads them right before their first use and waits on the spot)
   using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
   const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
@@ -984,7 +996,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
     int act[A];
 #pragma unroll
     for (int a = 0; a < A; a++) act[a] = ac.ld(a);
-    if constexpr (!LDS) tb = stage_tables<false>(p.tables, p.n16, p.quot_bytes);
+    if constexpr (!LDS) tb = stage_tables<false>(tables_, p.n16, p.quot_bytes);
     Env<A, M> e;
     unpack<A, M>(e, w);
     const int err_before = e.err;
@@ -998,7 +1010,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
     comp = e.completed;
     err = e.err != err_before;
     ShapeQ<B> sq;
-    shaping_lookup<B>(L, tb.quot, sin, sld, sq OC_STAMP_PASS);   // quotient loads ahead of the stores
+    shaping_lookup<B>(L, inv_max_path_, sin, sld, sq OC_STAMP_PASS);
     Out(p.reward, p.n, 1, i).st(0, reward);
     Out(p.done, p.n, 1, i).st(0, done);
     if (done && p.auto_reset) {
@@ -1204,8 +1216,8 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     // the output pointers are needed hundreds of instructions from here, where the compiler
     // would place their scalar loads -- and a wait on them -- in the middle of the step; fetch
     // them now, under the wait for the state that has to be served anyway
-    asm volatile("" ::"s"(tb.dist), "s"(tb.quot), "s"(p.obs), "s"(p.timestep), "s"(p.reward), "s"(p.done),
-                 "s"(p.sparse), "s"(p.auto_reset));
+    asm volatile("" ::"s"(tb.dist), "s"(p.obs), "s"(p.timestep), "s"(p.reward), "s"(p.done),
+                 "s"(p.sparse), "s"(p.auto_reset), "s"(p.R.inv_T), "s"(p.R.inv_max_path));
     Env<A, M> e;
     unpack<A, M>(e, w);
     OC_STAMP(1);   // state + actions arrived
@@ -1241,7 +1253,7 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
 #pragma unroll
     for (int r = 0; r < WS; r++) st.st(r, w[r]);
     ShapeQ<2> sq;
-    shaping_lookup<2>(L, tb.quot, sin, sld, sq OC_STAMP_PASS);   // quotient loads ahead of the obs stores
+    shaping_lookup<2>(L, p.R.inv_max_path, sin, sld, sq OC_STAMP_PASS);
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
@@ -1303,7 +1315,7 @@ int launch(K kernel, const Args &args, int64_t n, void *stream, size_t lds_bytes
 template <typename K>
 int launch_st(K kernel, const StepArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
   return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.metrics, a.n,
-                  (int32_t)block_size_for(n), a);
+                  (int32_t)block_size_for(n), a.tables, a.R.inv_max_path, a);
 }
 template <typename K>
 int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
@@ -1368,6 +1380,7 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
   h.W = W; h.H = H; h.A = A; h.M = M; h.S = S; h.max_path = b[OC_LV_MAX_PATH]; h.ncells = nc;
   run.T = b[OC_LV_T];
   run.inv_T = run.T ? 1.0 / (double)run.T : 0.0;
+  run.inv_max_path = 1.0 / (double)b[OC_LV_MAX_PATH];
   run.allergic = (uint32_t)b[OC_LV_ALLERGIC];
   const int32_t *cells = b + b[OC_LV_OFF_CELLS];
   const int32_t *ag = b + b[OC_LV_OFF_AGENTS], *it = b + b[OC_LV_OFF_ITEMS];
@@ -1541,7 +1554,7 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   const int32_t *dist = b + b[OC_LV_OFF_DIST];
   // tables buffer: the quotients k / MAX_PATH for every numerator the shaping formula can
   // form (correctly rounded fp64 division, as CPython's int / int), then the u8 distances
-  lv->quot_bytes = (int32_t)(sizeof(double) * h.nquot);
+  lv->quot_bytes = 0;   // (until round-1 v11: a table of fp64 quotients k / max_path came first)
   // ... then, in the last 64 bytes, the Counter tiles (x | y<<4) for random placement
   const size_t bytes = (((size_t)lv->quot_bytes + (size_t)nc * nc + 15) & ~(size_t)15) + OC_MAX_COUNTERS;
   lv->n16 = (int32_t)(bytes / 16);
@@ -1551,8 +1564,6 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
     return fail(OC_E_BADARG, "oc_level_create: out of memory");
   }
   memset(img, 0, bytes);
-  double *quot = (double *)img;
-  for (uint32_t k = 0; k < h.nquot; k++) quot[k] = (double)(int)k / (double)h.max_path;
   for (int i = 0; i < nc * nc; i++) img[lv->quot_bytes + i] = (uint8_t)dist[i];
   {
     const int32_t *ct = b + b[OC_LV_OFF_COUNTERS];
