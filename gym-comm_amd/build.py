@@ -15,7 +15,7 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          # leading scalar kernel arguments (k_multi_step) arrive in SGPRs at wave launch
-         "-mllvm", "-amdgpu-kernarg-preload-count=8"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=9"]
 # experiment switches (e.g. OC_HIP_EXTRA_FLAGS=-DOC_TABLES_IN_LDS); they enter the
 # specialisation cache key, so variants never collide
 FLAGS += [f for f in os.environ.get("OC_HIP_EXTRA_FLAGS", "").split() if f]

@@ -859,7 +859,6 @@ struct MetricsSlot {
 //                workgroups (n = 131072: 12.1 us vs 13.3 us), which lose overall.
 // Full sweep: profiles/r01_v3_block_lds_sweep.txt.
 struct Tables {
-  const double *quot;
   const uint8_t *dist;
   const uint8_t *counters;  // Counter tiles (x | y<<4), world order, 64 bytes
 };
@@ -883,12 +882,10 @@ __device__ __forceinline__ Tables stage_tables(const void *__restrict__ tables, 
     if (i2 < n16) oc_lds[i2] = t2;
     if (i3 < n16) oc_lds[i3] = t3;
     __syncthreads();
-    tb.quot = (const double *)oc_lds;
     tb.dist = (const uint8_t *)oc_lds + quot_bytes;
     tb.counters = (const uint8_t *)oc_lds + (n16 * 16 - OC_MAX_COUNTERS);
   } else {
-    tb.quot = (const double *)tables;
-    tb.dist = (const uint8_t *)tables + quot_bytes;
+    tb.dist = (const uint8_t *)tables;   // quot_bytes is 0 since the quotient table went (v12)
     tb.counters = (const uint8_t *)tables + (n16 * 16 - OC_MAX_COUNTERS);
   }
   return tb;
@@ -972,13 +969,16 @@ struct StepArgs {
 // (leading scalars: preloaded kernel arguments, see k_multi_step)
 template <int A, int M, bool LDS, bool WT>
 __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32_t *const actions_,
-                                              int64_t *const metrics_, const int64_t n_, const int32_t block_,
-                                              const void *const tables_, const double inv_max_path_,
-                                              const StepArgs p) {
-  // (tables_ / inv_max_path_ too: this kernel runs at the SGPR limit with 3-4 agents, and the
-  // compiler otherwise loads them right before their first use and waits on the spot)
+                                              int64_t *const metrics_, const int64_t n_, const int32_t launch_,
+                                              const int32_t T_, const void *const tables_,
+                                              const double inv_max_path_, const StepArgs p) {
+  // (tables_ / inv_max_path_ / T_ and, packed into launch_ = block | auto_reset << 16, the
+  // auto-reset flag too: this kernel runs at the SGPR limit with 3-4 agents, and the compiler
+  // otherwise loads each of them right before its first use and waits on the spot)
   using Out = RowsT<WT ? AUX_WT : 0>;
   const LevelHdr &L = OC_HDR(p);
+  const int block_ = launch_ & 0xFFFF;
+  const bool auto_reset_ = (launch_ >> 16) & 1;
   const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
   const bool valid = i < (int)n_;
   Tables tb;   // (global variant: formed after the state loads are issued, see k_multi_step)
@@ -1006,14 +1006,16 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
 #ifdef OC_STAMPS
     unsigned long long oc_tt[16];
 #endif
-    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
+    RunCfg R = p.R;
+    R.T = T_;   // the preloaded copy
+    env_step<A, M>(L, R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     ShapeQ<B> sq;
     shaping_lookup<B>(L, inv_max_path_, sin, sld, sq OC_STAMP_PASS);
     Out(p.reward, p.n, 1, i).st(0, reward);
     Out(p.done, p.n, 1, i).st(0, done);
-    if (done && p.auto_reset) {
+    if (done && auto_reset_) {
 #pragma unroll
       for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
       place_items<A, M>(L, tb, p.placement, p.rng, p.n, i, w);
@@ -1315,7 +1317,8 @@ int launch(K kernel, const Args &args, int64_t n, void *stream, size_t lds_bytes
 template <typename K>
 int launch_st(K kernel, const StepArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
   return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.metrics, a.n,
-                  (int32_t)block_size_for(n), a.tables, a.R.inv_max_path, a);
+                  (int32_t)(block_size_for(n) | ((a.auto_reset ? 1 : 0) << 16)), a.R.T, a.tables,
+                  a.R.inv_max_path, a);
 }
 template <typename K>
 int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
