@@ -13,8 +13,8 @@ import torch
 from gym_comm_amd.batched import BatchedOvercooked
 
 NAMES = ["start->state+actions in regs", "collisions+interact (+ position lookups issued)",
-         "done/reward (+ Deliver lookups issued)", "state stores, distances consumed, quotient loads issued",
-         "obs x2 (stores issued)", "quotients arrive + fp64 sums", "shaped reward stored", "metrics"]
+         "done/reward (+ Deliver lookups issued)", "state stores, distances consumed, quotients formed",
+         "obs x2 (stores issued)", "fp64 sums", "shaped reward stored", "metrics"]
 
 
 def main():
