@@ -657,6 +657,9 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
 #pragma unroll
     for (int i = 0; i < M; i++) ipb[i] = ipos(e.iw[i]);
     shaping_issue_pos<B, M>(L, dist, sin, ipb, sld);
+    // keep the lookups HERE: left alone, the scheduler sinks them below done/reward, ~40
+    // instructions ahead of their first use
+    __builtin_amdgcn_sched_barrier(0);
   }
   OC_STAMP(2);
   // ---- done (:243-270) and reward (:399-432) ---------------------------------
