@@ -717,6 +717,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     }
   }
   shaping_issue_del<B>(L, dist, sin, sld);
+  __builtin_amdgcn_sched_barrier(0);   // ... and these ahead of the caller's stores
   OC_STAMP(3);   // done/reward computed, distance loads issued
 }
 
