@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the batched Overcooked stepper (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch: the fused ``oc_multi_step`` launch
@@ -12,11 +12,33 @@ actions) are resident in HBM before the timed region.  Envs are independent, so 
 N shards of the same per-GPU batch with no data-path collective ("weak" scaling); RCCL
 only all-gathers the 64-byte metrics vector at the end of the rollout.
 
+``--gpus N`` (N > 1) started WITHOUT torchrun (no RANK in the environment) starts the N
+ranks itself -- fresh child processes through ``torch.distributed.run``, before this
+process has touched a GPU -- and relays rank 0's line; it never reports a 1-GPU run for an
+N-GPU request.
+
+Timing: blocks of EXACTLY ``--steps`` (K) steps are run back to back -- ``reps`` of them,
+enough for >= 50 ms of GPU time (``--reps`` overrides) -- inside ONE region bracketed by
+barrier + synchronize on both sides.  Blocks are hipGraph replays; a K shorter than the
+256-step graph window shares one replay with the next blocks (``blocks_per_replay``), so the
+~10 us between two graph launches is not charged to 20 steps.  A HIP event on the launch
+stream separates the replays; ``ms_per_step`` is the MEDIAN block time / K (MAX over ranks):
+a short ``--steps`` gives the steady-state number, not one launch + sync latency.  The wall
+clock over the whole region is reported beside it (``ms_per_step_wall``).
+
+``--mode closed-loop`` measures the same kernel with policies in the loop (an ego and a
+partner MLP on the observations, actions sampled on the device, episode statistics; one
+hipGraph per step block) through ``OvercookedVecEnv``; it is reported with its own metric
+name, never instead of the headline.
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,21 +51,48 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WINDOW = 256                # pre-generated action steps, cycled
+MIN_TIMED_MS = 50.0         # GPU time the timed region must cover (reps is derived from it)
+ELEM = {"int32": 4, "int8": 1, "float32": 4}
 
 
-def algorithmic_bytes_per_env_step(A, M, S, C, with_obs):
-    """4 B x (2*W_state + A + W_out + W_obs), int32 SoA accounting with
-    W_state = 3A + 5M + 1 + 2S, W_out = 6, W_obs = 2*(23 + S + 2C)."""
+def survey_bytes_per_env_step(A, M, S, C, with_obs, obs_elem=4):
+    """4 B x (2*W_state + A + W_out) + elem x W_obs, int32-per-FIELD accounting
+    with W_state = 3A + 5M + 1 + 2S, W_out = 6, W_obs = 2*(23 + S + 2C).  The packed layout
+    moves fewer bytes than this (see layout_bytes_per_env_step), so a rate formed with it is a
+    labelled secondary figure, not the roofline fraction."""
     w_state = 3 * A + 5 * M + 1 + 2 * S
     w_obs = 2 * (23 + S + 2 * C) if with_obs else 0
-    return 4 * (2 * w_state + A + 6 + w_obs)
+    return 4 * (2 * w_state + A + 6) + obs_elem * w_obs
 
 
-def parse():
+def layout_bytes_per_env_step(A, M, S, C, wrapper, obs_elem=4, metrics=True):
+    """Bytes one env-step really moves with this repo's layout (include/oc_hip.h):
+    read  : A+M+2 packed state words, the action rows;
+    write : the state words, and for the fused wrapper step the 2 comm words, 2 viewers x
+            (22+S+2C) observation rows, timestep f64, shaped reward f64, done, sparse reward;
+            for the base step reward, done, 2 x f64 shaping;
+    plus six 8-byte no-return atomics per 64 envs for the metrics.
+    Returns (read, written)."""
+    state = 4 * (A + M + 2)
+    if wrapper:
+        read = state + 4 * 4
+        written = state + 2 * 4 + 2 * (22 + S + 2 * C) * obs_elem + 8 + 8 + 4 + 4
+    else:
+        read = state + 4 * A
+        written = state + 4 + 4 + 2 * 8
+    if metrics:
+        written += 6 * 8 / 64.0
+    return read, written
+
+
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20000)
-    p.add_argument("--warmup", type=int, default=512)
+    p.add_argument("--steps", type=int, default=2048)
+    p.add_argument("--warmup", type=int, default=256)
+    p.add_argument("--reps", type=int, default=0,
+                   help="timed repetitions of the --steps block (0 = enough for %.0f ms of GPU time)" % MIN_TIMED_MS)
+    p.add_argument("--mode", default="open-loop", choices=["open-loop", "closed-loop"])
     p.add_argument("--level", default="open-divider_tomato")
     p.add_argument("--agents", type=int, default=2)
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
@@ -53,11 +102,38 @@ def parse():
     p.add_argument("--graph-steps", type=int, default=WINDOW)
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N>1 on one GPU)")
     p.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    p.add_argument("--obs-dtype", default="int32", choices=["int32", "int8", "float32"],
+    p.add_argument("--obs-dtype", default="int32", choices=sorted(ELEM),
                    help="observation rows: int32 (SURVEY 8(d) accounting), int8 (4x fewer bytes) or float32")
+    p.add_argument("--hidden", type=int, default=64, help="closed-loop: width of the two policy MLPs")
+    p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
-    return p.parse_args()
+    return p.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as fresh children (this process has not
+    touched a GPU), one per LOCAL_RANK, and let rank 0's JSON line through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "2")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit %d)\n" % (args.gpus, proc.returncode))
+        return proc.returncode or 1
+    out = json.loads(lines[-1])
+    if out.get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: asked for %d ranks, the run reports %r\n" % (args.gpus, out.get("n_gpus")))
+        return 1
+    print(lines[-1], flush=True)
+    return 0
 
 
 def host_threads():
@@ -120,8 +196,49 @@ def cpu_baseline(level_blob, A, C, wrapper, seconds):
                       % (n, steps, el, cores, steps1, el1)}
 
 
+class StepBlocks:
+    """K steps as hipGraph replays (K-step graphs of up to `G` steps + one tail graph), or as
+    eager launches."""
+
+    def __init__(self, step_fn, stream, G, use_graph):
+        self.step_fn, self.stream, self.G, self.use_graph = step_fn, stream, G, use_graph
+        self.graphs = {}
+
+    def _graph(self, length):
+        if length not in self.graphs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                for k in range(length):
+                    self.step_fn(k)
+            self.graphs[length] = g
+        return self.graphs[length]
+
+    def prepare(self, counts):
+        if not self.use_graph:
+            return
+        for cnt in counts:
+            if cnt >= self.G:
+                self._graph(self.G)
+            if cnt % self.G:
+                self._graph(cnt % self.G)
+
+    def run(self, steps):
+        if self.use_graph:
+            k = 0
+            while steps - k >= self.G:
+                self.graphs[self.G].replay()
+                k += self.G
+            if steps - k:
+                self.graphs[steps - k].replay()
+            return
+        for k in range(steps):
+            self.step_fn(k)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))           # before anything here touches a GPU
     # native libraries (RCCL's version banner, gloo's rank chatter) print to fd 1; keep
     # stdout clean for the ONE JSON line by pointing fd 1 at stderr until we print it
     sys.stdout.flush()
@@ -130,7 +247,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
@@ -146,147 +263,203 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    from gym_comm_amd import dist as ocdist
     from gym_comm_amd.batched import BatchedOvercooked
     wrapper = args.agents == 2
+    closed = args.mode == "closed-loop"
+    if closed and not wrapper:
+        raise SystemExit("--mode closed-loop drives the 2-agent gym_comm wrapper")
     n = args.envs
-    env = BatchedOvercooked(args.level, num_agents=args.agents, num_envs=n,
-                            max_num_timesteps=args.T, num_communication=args.comm,
-                            communication_on=True, fow_radius=2, device=dev, auto_reset=True,
-                            obs_dtype=getattr(torch, args.obs_dtype))
-    lv = env.level
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    if wrapper:
-        hi = torch.tensor([4, args.comm, 4, args.comm], device=dev).view(1, 4, 1)
-        acts = (torch.rand((WINDOW, 4, n), generator=gen, device=dev) * hi).to(torch.int32).contiguous()
-        step_fn = env.multi_step
-    else:
-        acts = torch.randint(0, 4, (WINDOW, args.agents, n), generator=gen, device=dev,
-                             dtype=torch.int32)
-        step_fn = env.step
-    acts = [acts[k].contiguous() for k in range(WINDOW)]
-
+    K = max(1, args.steps)
+    seed = ocdist.rank_seed(args.seed, rank)          # independent shard: actions AND placements
     stream = torch.cuda.Stream(device=dev)
     use_graph = not args.no_graph
     G = max(1, min(args.graph_steps, WINDOW))
-    graph = None
+
+    if closed:
+        from gym_comm_amd.vec_env import OvercookedVecEnv, MLPPolicy, TorchPolicyPartner
+        arglist = dict(level=args.level, num_agents=2, max_num_timesteps=args.T,
+                       num_communication=args.comm, communication_on=True, fow_radius=2)
+        partner = TorchPolicyPartner(MLPPolicy(3, args.comm, hidden=args.hidden, seed=seed + 1).to(dev),
+                                     sample=True, seed=seed + 2, device=dev)
+        venv = OvercookedVecEnv(arglist, n, partner=partner, device=dev, seed=seed,
+                                obs_dtype=torch.float32)
+        env = venv._b
+        ego = TorchPolicyPartner(MLPPolicy(env.S, args.comm, hidden=args.hidden, seed=seed + 3).to(dev),
+                                 sample=True, seed=seed + 4, device=dev)
+        with torch.cuda.stream(stream):
+            venv.reset_tensors()
+            loop = venv.closed_loop(ego, graph=False)  # ego fwd -> partner fwd -> step (+ stats in-kernel)
+        step_fn = lambda k: loop.enqueue()             # captured K at a time by StepBlocks below
+        obs_elem = 4
+    else:
+        env = BatchedOvercooked(args.level, num_agents=args.agents, num_envs=n,
+                                max_num_timesteps=args.T, num_communication=args.comm,
+                                communication_on=True, fow_radius=2, device=dev, auto_reset=True,
+                                obs_dtype=getattr(torch, args.obs_dtype), seed=seed)
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        if wrapper:
+            hi = torch.tensor([4, args.comm, 4, args.comm], device=dev).view(1, 4, 1)
+            acts = (torch.rand((WINDOW, 4, n), generator=gen, device=dev) * hi).to(torch.int32).contiguous()
+            fn = env.multi_step
+        else:
+            acts = torch.randint(0, 4, (WINDOW, args.agents, n), generator=gen, device=dev,
+                                 dtype=torch.int32)
+            fn = env.step
+        acts = [acts[k].contiguous() for k in range(WINDOW)]
+        step_fn = lambda k: fn(acts[k % WINDOW])
+        obs_elem = ELEM[args.obs_dtype]
+    lv = env.level
+
+    blocks = StepBlocks(step_fn, stream, G, use_graph)
+    # A short --steps block (K < G) would be one small graph per block, and the ~10 us between two
+    # graph launches would be charged to 20 steps; `bpr` consecutive K-step blocks therefore share
+    # one graph replay (bpr * K <= G steps) and the replay time is divided by bpr.
+    bpr = max(1, G // K) if use_graph else 1
+    SB = bpr * K
     with torch.cuda.stream(stream):
         for k in range(max(1, min(args.warmup, 64))):    # touch everything before capture (module load,
-            step_fn(acts[k % WINDOW])                    # first-launch work): at least once, also for --warmup 0
+            step_fn(k)                                   # first-launch work): at least once, also for --warmup 0
         stream.synchronize()
-        tails = {}                                       # remainder length -> its own graph
-
-        def capture(length):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream):
-                for k in range(length):
-                    step_fn(acts[k % WINDOW])
-            return g
-
-        if use_graph:
-            graph = capture(G)
-            for cnt in (args.warmup, args.steps):        # a short --steps still runs as ONE graph launch
-                if cnt % G:
-                    tails.setdefault(cnt % G, capture(cnt % G))
-
-        def run(steps):
-            k = 0
-            if graph is not None:
-                while steps - k >= G:
-                    graph.replay()
-                    k += G
-                if steps - k in tails:
-                    tails[steps - k].replay()
-                    k = steps
-            while k < steps:
-                step_fn(acts[k % WINDOW])
-                k += 1
-
-        run(args.warmup)
+        blocks.prepare((args.warmup, SB))
+        blocks.run(args.warmup)
         stream.synchronize()
+
+        # reps: enough blocks for MIN_TIMED_MS of GPU time, from a short calibration
+        if args.reps > 0:
+            replays = max(1, -(-args.reps // bpr))
+        else:
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ncal = max(1, min(8, 4096 // SB))
+            c0.record(stream)
+            for _ in range(ncal):
+                blocks.run(SB)
+            c1.record(stream)
+            stream.synchronize()
+            replay_ms = max(c0.elapsed_time(c1) / ncal, 1e-3)
+            replays = int(min(4096, max(5, math.ceil(MIN_TIMED_MS / replay_ms))))
+        replays = int(ocdist.reduce_max([float(replays)], dev if args.backend == "nccl" else None)[0])
+        reps = replays * bpr                             # K-step blocks in the timed region
+
         if env.metrics is not None:
             env.metrics.zero_()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(replays + 1)]
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record(stream)
-        run(args.steps)
-        ev1.record(stream)
+        evs[0].record(stream)
+        for r in range(replays):
+            blocks.run(SB)                               # bpr blocks of EXACTLY K steps each
+            evs[r + 1].record(stream)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        ev_ms = ev0.elapsed_time(ev1)
+        wall = time.perf_counter() - t0
+        block_s = sorted(evs[r].elapsed_time(evs[r + 1]) / 1e3 / bpr for r in range(replays))
+        med_block_s = (block_s[replays // 2] if replays % 2
+                       else 0.5 * (block_s[replays // 2 - 1] + block_s[replays // 2]))
         rollout_metrics = env.metrics_vector()          # before the probe launches below
 
-        # kernel duration for the roofline: HIP events on the launch stream around
-        # individual launches (no graph), averaged
-        probe = 200
-        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(probe)]
-        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(probe)]
-        for k in range(probe):
-            e0[k].record(stream)
-            step_fn(acts[k % WINDOW])
-            e1[k].record(stream)
-        stream.synchronize()
-        per_launch_ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
-        launch_ms_bracketed = float(np.mean(per_launch_ms[probe // 10: probe - probe // 10]))
+        # kernel duration cross-check: HIP events on the launch stream around individual
+        # eager launches, trimmed mean (open-loop only: a closed-loop step is several kernels)
+        launch_ms_bracketed = None
+        if not closed:
+            probe = 200
+            e0 = [torch.cuda.Event(enable_timing=True) for _ in range(probe)]
+            e1 = [torch.cuda.Event(enable_timing=True) for _ in range(probe)]
+            for k in range(probe):
+                e0[k].record(stream)
+                step_fn(k)
+                e1[k].record(stream)
+            stream.synchronize()
+            per_launch_ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
+            launch_ms_bracketed = float(np.mean(per_launch_ms[probe // 10: probe - probe // 10]))
 
     # end-of-rollout metrics: the only collective on the path (RCCL all-gather, 64 B/rank)
-    from gym_comm_amd import dist as ocdist
     if dist is not None and args.backend != "nccl":
         rollout_metrics = rollout_metrics.cpu()          # gloo rehearsal: gather on host tensors
-    g = ocdist.gather_rollout_metrics(rollout_metrics, elapsed)
-    elapsed = g["elapsed_s"]
+    g = ocdist.gather_rollout_metrics(rollout_metrics, med_block_s)
+    med_block_s = g["elapsed_s"]                         # MAX over ranks
+    wall = ocdist.reduce_max([wall], dev if args.backend == "nccl" else None)[0]
     m = [g["total"][k] for k in ocdist.METRIC_NAMES]
 
     if rank == 0:
-        total_env_steps = n * world * args.steps
-        value = total_env_steps / elapsed
-        bytes_per = algorithmic_bytes_per_env_step(lv.num_agents, lv.num_items, lv.num_subtasks,
-                                                   args.comm, wrapper)
-        launch_s = (ev_ms / 1e3) / args.steps          # avg launch duration over the timed region
-        achieved = bytes_per * n / launch_s / 1e9
-        traffic = None
+        step_s = med_block_s / K
+        value = n * world / step_s
+        A, M, S = lv.num_agents, lv.num_items, lv.num_subtasks
+        rd, wr = layout_bytes_per_env_step(A, M, S, args.comm, wrapper, obs_elem)
+        survey = survey_bytes_per_env_step(A, M, S, args.comm, wrapper, obs_elem)
+        achieved = (rd + wr) * n / step_s / 1e9
+        survey_gbps = survey * n / step_s / 1e9
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not closed:
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
                 key = "%s_a%d_n%d" % (args.level, args.agents, n)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                if args.obs_dtype != "int32":
+                    key += "_" + args.obs_dtype
+                ent = tj.get(key, {})
+                traffic = ent.get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_src = "%s (stored rocprofv3 --pmc passes: %s; not collected in this run)" % (
+                        "profiles/traffic.json", ent.get("source"))
             except Exception:
                 traffic = None
+        kernel = "k_multi_step" if wrapper else "k_step"
         out = {
-            "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "metric": "env-steps/sec (whole node)" if not closed else
+                      "env-steps/sec (whole node), closed loop: ego + partner policy in the loop",
+            "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "reps": reps,
+            "ms_per_step": step_s * 1e3, "ms_per_step_wall": wall * 1e3 / (reps * K),
+            "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32" if closed else args.obs_dtype, "data": "synthetic",
             "config": {"workload": "%s, %d agents, %d parallel envs per GPU, T=%d, C=%d, %s"
                                    % (args.level, args.agents, n, args.T, args.comm,
+                                      ("closed loop: 2 MLP policies (hidden %d) + fused multi_step + "
+                                       "episode statistics" % args.hidden) if closed else
                                       "fused multi_step (step+obs)" if wrapper else "step only"),
+                       "mode": args.mode,
                        "level": args.level, "num_agents": args.agents, "envs_per_gpu": n,
-                       "max_num_timesteps": args.T, "launch": "hipgraph" if graph is not None else "eager",
-                       "obs_dtype": args.obs_dtype,
+                       "max_num_timesteps": args.T, "launch": "hipgraph" if use_graph else "eager",
+                       "obs_dtype": "float32" if closed else args.obs_dtype,
+                       "kernel_flavour": env.kernel_flavour,
                        "parallelism": "env-sharded x%d" % world},
             "agent_steps_per_sec": value * lv.num_agents,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         # the same with the bytes the PMC counters saw instead of SURVEY's int32-per-
-                         # field accounting (the packed state moves fewer): what the memory system did
-                         "traffic_gbps": (traffic / launch_s / 1e9) if traffic else None,
-                         "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "kernel": "k_multi_step" if wrapper else "k_step",
-                         "algorithmic_bytes_per_env_step": bytes_per,
-                         "avg_launch_us_timed_region": launch_s * 1e6,
-                         "avg_launch_us_event_bracketed": launch_ms_bracketed * 1e3},
+            "timing": {"what": "median over back-to-back blocks of `steps` steps (`reps` of them, "
+                               "`blocks_per_replay` per hipGraph replay), HIP events on the launch stream "
+                               "between replays, MAX over ranks",
+                       "blocks_per_replay": bpr, "replays": replays,
+                       "block_ms_min": block_s[0] * 1e3, "block_ms_median": med_block_s * 1e3,
+                       "block_ms_max": block_s[-1] * 1e3, "region_wall_s": wall},
             "rollout_metrics": {"env_steps": m[0], "episodes": m[1], "successes": m[2],
                                 "reward_sum": m[3], "completed_subtasks_sum": m[4], "errors": m[5]},
+            "per_rank": [{"rank": r, "env_steps": pr[0], "episodes": pr[1], "successes": pr[2],
+                          "reward_sum": pr[3]} for r, pr in enumerate(g["per_rank"])],
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not closed:
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "bytes": "the bytes this layout moves per env-step (packed state in/out, actions, comm, "
+                         "observation rows, timestep, rewards, done, metrics atomics)",
+                "layout_bytes_per_env_step": {"read": rd, "written": wr},
+                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_frac": (traffic / step_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                # SURVEY 8(d)'s int32-per-field accounting, which this layout does not move: a
+                # labelled secondary rate; as a "fraction" only while it stays below 1
+                "survey_bytes_per_env_step": survey, "survey_bytes_gbps": survey_gbps,
+                "frac_survey_bytes": (survey_gbps / HBM_PEAK_GBPS) if survey_gbps <= HBM_PEAK_GBPS else None,
+                "kernel": kernel,
+                "avg_launch_us_timed_region": step_s * 1e6,
+                "avg_launch_us_event_bracketed": launch_ms_bracketed * 1e3}
+        if not args.no_cpu_baseline and world == 1 and not closed:
             out["cpu_baseline"] = cpu_baseline(lv.blob, lv.num_agents, args.comm, wrapper,
                                                args.cpu_seconds)
         else:

@@ -9,11 +9,12 @@ import os
 from . import build as _build
 
 _I32P = ctypes.POINTER(ctypes.c_int32)
+ABI_VERSION = 2          # include/oc_hip.h: OC_ABI_VERSION
 
 SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destroy",
            "oc_level_spec_source", "oc_is_specialized",
            "oc_metrics_slots", "oc_state_words", "oc_obs_rows", "oc_reset", "oc_step", "oc_obs",
-           "oc_obs_image", "oc_multi_step"]
+           "oc_obs_image", "oc_image_words", "oc_multi_step", "oc_random_actions"]
 
 
 class ObsCfg(ctypes.Structure):
@@ -64,16 +65,19 @@ def _declare(L):
     L.oc_state_words.restype = ctypes.c_int32
     L.oc_obs_rows.argtypes = [vp, ctypes.c_int32]
     L.oc_obs_rows.restype = ctypes.c_int32
+    L.oc_image_words.argtypes = [vp]
+    L.oc_image_words.restype = ctypes.c_int32
     L.oc_reset.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, vp]
     L.oc_step.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, ctypes.c_int64, vp]
     L.oc_obs.argtypes = [vp, vp, vp, ctypes.POINTER(ObsCfg), vp, vp, ctypes.c_int64, vp]
     L.oc_obs_image.argtypes = [vp, vp, ctypes.c_int32, vp, vp, ctypes.c_int64, vp]
     L.oc_multi_step.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
-                                ctypes.c_int32, vp, vp, vp, ctypes.c_int64, vp]
+                                ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.c_int64, vp]
+    L.oc_random_actions.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
     for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_reset", "oc_step",
-              "oc_obs", "oc_obs_image", "oc_multi_step"):
+              "oc_obs", "oc_obs_image", "oc_multi_step", "oc_random_actions"):
         getattr(L, f).restype = ctypes.c_int
-    if L.oc_abi_version() != 1:
+    if L.oc_abi_version() != ABI_VERSION:
         raise OcError("liboc_hip.so ABI version mismatch")
     return L
 

@@ -40,7 +40,7 @@ class BatchedOvercooked:
                  communication_on=True, ego_led=False, fow_radius=2, ego_agent_idx=0,
                  device="cuda", subtask_order=None, placements=None, level_dir=None,
                  max_num_subtasks=14, auto_reset=True, track_metrics=True, specialize_level="auto",
-                 seed=0, placement_mode="rng", obs_dtype=torch.int32):
+                 seed=0, placement_mode="rng", obs_dtype=torch.int32, episode_stats=False):
         cfg = {"ALLERGIC": False, "BLIND": False, "CAN_MOVE": True}   # missing CAN_MOVE = True
         self.ego_config = dict(cfg, **(ego_config or {}))
         self.partner_config = dict(cfg, **(partner_config or {}))
@@ -86,6 +86,10 @@ class BatchedOvercooked:
                 ("comm", (2, n), torch.int32),                  # one-hot(0) (overcooked_env.py:89-91)
                 ("obs", (2, self.F, n), obs_dtype), ("timestep", (n,), torch.float64),
                 ("shaped_reward", (n,), torch.float64)]
+        if episode_stats:           # kept by the fused kernel (include/oc_hip.h: ep_return / ep_length)
+            spec += [("ep_return", (n,), torch.float64), ("ep_length", (n,), torch.int32)]
+        else:
+            self.ep_return = self.ep_length = None
         self._arena_layout, off = {}, 0
         for name, shape, dt in spec:
             nb = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
@@ -209,10 +213,10 @@ class BatchedOvercooked:
             a = self._ms_args = [self._h, dp(self.state), dp(self.comm), 0, ctypes.byref(self._wrap_cfg),
                                  dp(self.obs), dp(self.timestep), dp(self.shaped_reward), dp(self.done),
                                  dp(self.reward), 0, dp(self.metrics), dp(self.placement), dp(self.rng),
-                                 self.n, 0]
+                                 dp(self.ep_return), dp(self.ep_length), self.n, 0]
         a[3] = actions.data_ptr()
         a[10] = int(self.auto_reset if auto_reset is None else auto_reset)
-        a[15] = self._raw_stream()
+        a[17] = self._raw_stream()
         if torch.cuda.current_device() == self._dev_index:
             rc = self._L.oc_multi_step(*a)
         else:
@@ -222,22 +226,29 @@ class BatchedOvercooked:
             _lib.check(rc, "oc_multi_step", self._L)
         return self.obs, self.timestep, self.shaped_reward, self.done
 
-    def observe_image(self, radius: Optional[int] = None):
+    def observe_image(self, radius: Optional[int] = None, packed: bool = False):
         """Image-style fog-of-war observation of both viewers
         (get_partial_observability_FOW, overcooked_env.py:161-202).  Returns
-        (maps int8 [2][7][W][H][n] -- a view of the kernel's [2][7*W*H][n] rows --,
-        holding int8 [2][n])."""
+        (maps int8 [2][7][W][H][n], holding int8 [2][n]).  The kernel writes four consecutive
+        int8 rows of an env per dword ([2][ceil(7WH/4)][n] int32, include/oc_hip.h); the
+        [2][7][W][H][n] result is one re-layout copy of that -- `packed=True` returns the
+        kernel's tensor itself."""
         lv = self.level
         if getattr(self, "_image", None) is None:
-            self._image = torch.zeros((2, 7 * lv.width * lv.height, self.n), dtype=torch.int8,
-                                      device=self.device)
+            self._image_words = self._L.oc_image_words(self._h)
+            self._image = torch.zeros((2, self._image_words, self.n), dtype=torch.int32, device=self.device)
             self._holding = torch.zeros((2, self.n), dtype=torch.int8, device=self.device)
         r = self._obs_cfg.fow_radius if radius is None else int(radius)
         with self._on_device():
             _lib.check(self._L.oc_obs_image(self._h, self._p(self.state), r, self._p(self._image),
                                             self._p(self._holding), self.n, self._stream()),
                        "oc_obs_image", self._L)
-        return self._image.view(2, 7, lv.width, lv.height, self.n), self._holding
+        if packed:
+            return self._image, self._holding
+        rows = 7 * lv.width * lv.height
+        q = self._image_words
+        img = self._image.view(torch.int8).view(2, q, self.n, 4).permute(0, 1, 3, 2).reshape(2, 4 * q, self.n)
+        return img[:, :rows].reshape(2, 7, lv.width, lv.height, self.n), self._holding
 
     def completed_subtasks(self):
         """completed_subtasks of every env as int32 [S][n] (from the packed state)."""
@@ -268,7 +279,10 @@ class BatchedOvercooked:
         return out
 
     def metrics_vector(self):
-        """int64[8] totals (sum over the per-wave slots), on the device."""
+        """int64[8] totals (sum over the per-wave slots), on the device; None when the env was
+        built with track_metrics=False."""
+        if self.metrics is None:
+            return None
         return self.metrics.sum(dim=0)
 
     def read_metrics(self):

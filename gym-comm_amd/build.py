@@ -46,8 +46,10 @@ def build(force=False, verbose=False, extra_flags=()):
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCTRACER", "HSA_TOOLS_LIB"))}
     try:
-        subprocess.check_call(cmd)
+        subprocess.check_call(cmd, env=env)
         os.replace(tmp, LIB)
     finally:
         if os.path.exists(tmp):

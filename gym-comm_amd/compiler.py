@@ -65,60 +65,67 @@ class _Action:
         return "%s(%s)" % (self.kind, ", ".join(self.args))
 
 
-def _merge_action(a, b, pre=None):
-    # recipe_planner/utils.py:131-141: default pre = [Chopped(a), Merged(b)]
-    if pre is None:
-        pre = ["Chopped(%s)" % a, "Merged(%s)" % b]
-    post = ["Merged(%s)" % _join(a.split("-") + b.split("-"))]
-    return _Action("Merge", (a, b), pre, post)
+def _holding_predicate(names):
+    """The STRIPS predicate under which the planner tracks a pile of contents: a bare Plate is
+    ``Fresh(Plate)`` (plates are never chopped), a single food must be ``Chopped``, anything
+    with two or more contents is ``Merged(<names joined>)``.  Every Merge precondition of the
+    reference's action table is this function of the two argument piles (the explicit
+    preconditions at recipe.py:24-25,46-47,58-59,64-65 and the default ``[Chopped(arg1),
+    Merged(arg2)]`` of recipe_planner/utils.py:131-141 all agree with it)."""
+    names = tuple(names)
+    if names == ("Plate",):
+        return "Fresh(Plate)"
+    if len(names) == 1:
+        return "Chopped(%s)" % names[0]
+    return "Merged(%s)" % _join(names)
 
 
 def recipe_actions(recipe_name: str) -> Tuple[Dict[tuple, _Action], str]:
-    """Action set of one recipe and its goal predicate (recipe.py:5-66).
+    """Action set of one recipe and its goal predicate, derived from the rule behind the
+    reference's table (recipe_planner/recipe.py:5-66) rather than from its construction order:
 
-    Actions hash/compare on (name, args) only (recipe_planner/utils.py:83-89), so a
-    second action with the same name and args never replaces the first."""
+      * ``Get(Plate)`` and, per ingredient, ``Get`` and ``Chop``;
+      * ``Deliver`` of the fully plated dish;
+      * a ``Merge(a, b)`` for every way the table lets two piles meet, each with the
+        preconditions ``_holding_predicate`` gives the piles and ``Merged(a + b)`` as effect:
+        any pile of ingredients U goes onto the bare Plate; and for |U| >= 2 a single
+        ingredient x meets the rest of U -- bare, with the rest already plated, or with x itself
+        already plated.  In that last family the table names a lone food first and the plated x
+        second, but the plated x first when the rest is a pile.
+
+    Actions are identified by (name, args) (recipe_planner/utils.py:83-89); since the
+    preconditions are a function of the args, no two constructions of the same key disagree."""
     if recipe_name not in RECIPE_INGREDIENTS:
         raise ValueError("unknown recipe class %r" % recipe_name)
+    ings = sorted(RECIPE_INGREDIENTS[recipe_name])
+    plate = ("Plate",)
     acts: Dict[tuple, _Action] = {}
 
-    def add(a):
-        acts.setdefault(a.key, a)
+    def put(kind, args, pre, post):
+        acts.setdefault((kind, tuple(args)), _Action(kind, args, pre, post))
 
-    def get(x):
-        return _Action("Get", (x,), ["None"], ["Fresh(%s)" % x, "None"])
+    for x in ["Plate"] + ings:
+        put("Get", (x,), ["None"], ["Fresh(%s)" % x, "None"])
+    for x in ings:
+        put("Chop", (x,), ["Fresh(%s)" % x], ["Chopped(%s)" % x])
+    dish = _join(ings + ["Plate"])
+    put("Deliver", (dish,), ["Merged(%s)" % dish], ["Delivered(%s)" % dish])
 
-    add(get("Plate"))
-    names = []
-    for ing in RECIPE_INGREDIENTS[recipe_name]:
-        names.append(ing)
-        add(get(ing))
-        add(_Action("Chop", (ing,), ["Fresh(%s)" % ing], ["Chopped(%s)" % ing]))
-        add(_merge_action(ing, "Plate", ["Chopped(%s)" % ing, "Fresh(Plate)"]))
-    names = sorted(names)
-    full_plate = _join(names + ["Plate"])
-    add(_Action("Deliver", (full_plate,), ["Merged(%s)" % full_plate],
-                ["Delivered(%s)" % full_plate]))
-    for i in range(2, len(names) + 1):
-        for combo in combinations(names, i):
-            cj = _join(combo)
-            add(_merge_action(cj, "Plate", ["Merged(%s)" % cj, "Fresh(Plate)"]))
-            for item in combo:
-                rem = [c for c in combo if c != item]
-                rem_str = _join(rem)
-                plate_str = _join([item, "Plate"])
-                rem_plate_str = _join(rem + ["Plate"])
-                if len(rem) == 1:
-                    add(_merge_action(item, rem_str,
-                                      ["Chopped(%s)" % item, "Chopped(%s)" % rem_str]))
-                    add(_merge_action(rem_str, plate_str))
-                    add(_merge_action(item, rem_plate_str))
-                else:
-                    add(_merge_action(item, rem_str))
-                    add(_merge_action(plate_str, rem_str,
-                                      ["Merged(%s)" % plate_str, "Merged(%s)" % rem_str]))
-                    add(_merge_action(item, rem_plate_str))
-    return acts, "Delivered(%s)" % full_plate
+    meetings = []                               # (pile a, pile b) in the table's argument order
+    for size in range(1, len(ings) + 1):
+        for pile in combinations(ings, size):
+            meetings.append((pile, plate))
+            if size == 1:
+                continue
+            for x in pile:
+                rest = tuple(n for n in pile if n != x)
+                meetings.append(((x,), rest))
+                meetings.append(((x,), rest + plate))
+                meetings.append((rest, (x,) + plate) if len(rest) == 1 else ((x,) + plate, rest))
+    for a, b in meetings:
+        put("Merge", (_join(a), _join(b)), [_holding_predicate(a), _holding_predicate(b)],
+            ["Merged(%s)" % _join(a + b)])
+    return acts, "Delivered(%s)" % dish
 
 
 def plan_subtasks(recipe_name: str, item_types: Sequence[int], max_path_length: int = 14):

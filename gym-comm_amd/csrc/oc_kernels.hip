@@ -523,6 +523,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
 #pragma unroll
   for (int a = 0; a < A; a++) {
     int c = act_in[a];
+    if ((unsigned)c > 4u) e.err |= OC_ERR_ACTION;   // no such NAV action: flagged, executed as (0, 0)
     c = (unsigned)c > 4u ? OC_ACT_NOOP : c;
     act[a] = c;
     if constexpr (OC_BORDER_CLOSED) {
@@ -824,7 +825,8 @@ struct MetricsSlot {
                                       int completed_bits, bool err) {
     if (!has_metrics) return;  // uniform
     const bool fin = valid && done;
-    // word A: reward (<= 16 + 3 * MAX_DELS < 64 -> 12-bit sum) | completed subtasks of a finished episode (<= 32 -> 11-bit sum)
+    // word A: reward (<= 32 + 3 * MAX_DELS < 64 -> 12-bit sum) | completed subtasks of a finished
+    // episode (<= OC_MAX_SUBTASKS = 32 per lane, 64 lanes -> a 12-bit sum)
     // word B: valid | done | success | error, 7 bits each (a count up to 64)
     const int a = (valid ? reward : 0) | ((fin ? __popc(completed_bits) : 0) << 12);
     const int b = (valid ? 1 : 0) | ((fin ? 1 : 0) << 7) | (((valid && success) ? 1 : 0) << 14) |
@@ -834,7 +836,9 @@ struct MetricsSlot {
     // lane k picks counter k out of the two totals: a per-lane (word, offset, width) from
     // three packed constants -- plain VALU selects, no divergent control flow
     constexpr unsigned OFF = 0u | 7u << 5 | 14u << 10 | 0u << 15 | 12u << 20 | 21u << 25;    // 5 bits per lane
-    constexpr unsigned WID = 7u | 7u << 5 | 7u << 10 | 12u << 15 | 11u << 20 | 7u << 25;
+    constexpr unsigned WID = 7u | 7u << 5 | 7u << 10 | 12u << 15 | 12u << 20 | 7u << 25;
+    static_assert(64 * OC_MAX_SUBTASKS < (1 << 12) && 64 * (OC_MAX_SUBTASKS + 3 * MAX_DELS) < (1 << 12),
+                  "wave sums must fit their 12-bit fields");
     static_assert(OC_MET_ENV_STEPS == 0 && OC_MET_EPISODES == 1 && OC_MET_SUCCESSES == 2 &&
                   OC_MET_REWARD_SUM == 3 && OC_MET_COMPLETED_SUM == 4 && OC_MET_ERRORS == 5, "slot order");
     const unsigned lane = threadIdx.x & 63, k5 = (lane < 6 ? lane : 0) * 5;
@@ -1075,7 +1079,7 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
 struct ImageArgs {
   LevelHdr L;
   const int32_t *state;
-  int8_t *out;        // [2][7*W*H][n]
+  int32_t *out;       // [2][ceil(7*W*H / 4)][n]: four consecutive rows of an env per dword
   int8_t *holding;    // [2][n]
   int64_t n;
   int32_t radius;
@@ -1083,11 +1087,13 @@ struct ImageArgs {
 
 // OvercookedMultiEnv.get_partial_observability_FOW for both viewers
 // (gym_comm/envs/overcooked_env.py:161-202; the image-style observation the reference
-// defines but does not call).  Row (k*W + x)*H + y of viewer v holds plane k at cell (x, y)
-// for n consecutive envs (int8, one 64-byte store per wave and row): plane 0 the tile type,
-// planes 1.. "agent i stands here" (:183-185 -- with 3+ agents these overwrite the content
-// planes, as in the reference), planes 3 + channel the contents (Food: state_index + 1,
-// Plate: 1); cells farther than `radius` (manhattan) from the viewer are -1 in every plane.
+// defines but does not call).  Row r = (k*W + x)*H + y of viewer v holds plane k at cell (x, y):
+// plane 0 the tile type, planes 1.. "agent i stands here" (:183-185 -- with 3+ agents these
+// overwrite the content planes, as in the reference), planes 3 + channel the contents (Food:
+// state_index + 1, Plate: 1); cells farther than `radius` (manhattan) from the viewer are -1 in
+// every plane.  Rows are int8; a lane packs FOUR consecutive rows of its env into one dword
+// (little-endian, zero padded past the last row), so a wave stores 256 contiguous bytes per
+// instruction: 172 dword stores per viewer-pair and wave at 7x7 instead of 686 byte stores.
 template <int A, int M>
 __global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
   const LevelHdr &L = OC_HDR(p);
@@ -1101,34 +1107,41 @@ __global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
   Env<A, M> e;
   unpack<A, M>(e, w);
   const int W = L.W, H = L.H;
-  const int rows = 7 * W * H;
+  const int rows = 7 * W * H, R4 = (rows + 3) >> 2;
   const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(2 * rows * p.n), 0x00020000);
-  for (int x = 0; x < W; x++)
-    for (int y = 0; y < H; y++) {
-      const int c = y * W + x, cell = x | (y << 4);
-      int plane[7];
-      plane[0] = cell_type(L, c);
+      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(2 * R4 * p.n * 4), 0x00020000);
+  int k = 0, x = 0, y = 0;   // (plane, cell) of row r, advanced incrementally (uniform)
+  for (int r4 = 0; r4 < R4; r4++) {
+    unsigned pk[2] = {0u, 0u};
 #pragma unroll
-      for (int k = 1; k < 7; k++) plane[k] = 0;
+    for (int b = 0; b < 4; b++) {
+      if (4 * r4 + b < rows) {   // uniform
+        const int cell = x | (y << 4);
+        int val = k == 0 ? cell_type(L, y * W + x) : 0;
+        if (k >= 3) {   // uniform; world order is irrelevant: one writer per (plane, cell) value
 #pragma unroll
-      for (int m = 0; m < M; m++) {  // world order is irrelevant: one writer per (plane, cell) value
-        const int t = item_type(L, m);
-        const int v = t == OC_PLATE ? 1 : ichop(e.iw[m]) + 1;
+          for (int m = 0; m < M; m++)
+            if (item_type(L, m) + 3 == k)   // uniform
+              val = ipos(e.iw[m]) == cell ? (k == 3 + OC_PLATE ? 1 : ichop(e.iw[m]) + 1) : val;
+        }
 #pragma unroll
-        for (int k = 3; k < 7; k++) plane[k] = (t + 3 == k && ipos(e.iw[m]) == cell) ? v : plane[k];
-      }
+        for (int a = 0; a < A; a++)
+          if (k == a + 1) val = e.ap[a] == cell ? 1 : val;   // uniform test
 #pragma unroll
-      for (int a = 0; a < A; a++) plane[a + 1] = e.ap[a] == cell ? 1 : plane[a + 1];
-#pragma unroll
-      for (int v = 0; v < 2; v++) {
-        const bool fog = iabs(x - px(e.ap[v])) + iabs(y - py(e.ap[v])) > p.radius;
-#pragma unroll
-        for (int k = 0; k < 7; k++)
-          __builtin_amdgcn_raw_buffer_store_b8((char)(fog ? -1 : plane[k]), rsrc, (int)i,
-                                               (int)((v * rows + (k * W + x) * H + y) * p.n), AUX_WT);
+        for (int v = 0; v < 2; v++) {
+          const bool fog = iabs(x - px(e.ap[v])) + iabs(y - py(e.ap[v])) > p.radius;
+          pk[v] |= (unsigned)((fog ? -1 : val) & 255) << (8 * b);
+        }
+        if (++y == H) {
+          y = 0;
+          if (++x == W) x = 0, k++;
+        }
       }
     }
+#pragma unroll
+    for (int v = 0; v < 2; v++)
+      __builtin_amdgcn_raw_buffer_store_b32((int)pk[v], rsrc, (int)i * 4, (int)((v * R4 + r4) * p.n * 4), AUX_WT);
+  }
   p.holding[i] = e.ahp[0] != 0;
   p.holding[p.n + i] = e.ahp[1] != 0;
 }
@@ -1161,6 +1174,17 @@ __global__ void __launch_bounds__(256) k_reset(const ResetArgs p) {
   for (int r = 0; r < WS; r++) p.state[(int64_t)r * p.n + i] = w[r];
 }
 
+// Uniform random (move, comm) indices of one player (include/oc_hip.h: oc_random_actions)
+__global__ void __launch_bounds__(256) k_random_actions(uint32_t *rng, int32_t *move_row, int32_t *comm_row,
+                                                        uint32_t num_comm, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t st = rng[i];
+  move_row[i] = (int32_t)__umulhi(pcg32(st), 4u);
+  comm_row[i] = (int32_t)__umulhi(pcg32(st), num_comm);
+  rng[i] = st;
+}
+
 struct MultiArgs {
   LevelHdr L;
   RunCfg R;
@@ -1177,6 +1201,8 @@ struct MultiArgs {
   int64_t *metrics;
   const int32_t *placement;
   uint32_t *rng;
+  double *ep_return;     // per-env episode statistics (include/oc_hip.h), NULL = off
+  int32_t *ep_length;
   int64_t n;
   int32_t auto_reset;
   oc_wrap_cfg cfg;
@@ -1224,21 +1250,39 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     // them now, under the wait for the state that has to be served anyway
     asm volatile("" ::"s"(tb.dist), "s"(p.obs), "s"(p.timestep), "s"(p.reward), "s"(p.done),
                  "s"(p.sparse), "s"(p.auto_reset), "s"(p.R.inv_T), "s"(p.R.inv_max_path));
+    // episode statistics: the running return / length and the previous step's done flag are
+    // loaded now, with the state, and consumed after the last store of the step
+    double ep_ret = 0.0;
+    int ep_len = 0, prev_done = 0;
+    if (p.ep_return != nullptr) {   // uniform
+      typedef int v2i __attribute__((ext_vector_type(2)));
+      const Rows er(p.ep_return, n_, 1, i, 8);
+      ep_ret = __builtin_bit_cast(double, (v2i)__builtin_amdgcn_raw_buffer_load_b64(er.rsrc, er.voff, 0, 0));
+      ep_len = Rows(p.ep_length, n_, 1, i).ld(0);
+      prev_done = Rows(p.done, n_, 1, i).ld(0);
+    }
     Env<A, M> e;
     unpack<A, M>(e, w);
     OC_STAMP(1);   // state + actions arrived
-    // comm one-hots (:227-246)
-    const int c0 = p.cfg.communication_on ? ego_cm : -1;
-    const int c1 = (p.cfg.communication_on && !p.cfg.ego_led) ? alt_cm : -1;
+    // comm one-hots (:227-246); an index the reference's one_hot[idx] = 1 would raise on is
+    // flagged (OC_ERR_ACTION) and sends nothing
+    const unsigned NC = (unsigned)p.cfg.obs.num_comm;
+    const bool ego_talks = p.cfg.communication_on, alt_talks = p.cfg.communication_on && !p.cfg.ego_led;
+    const bool bad_cm = (ego_talks && (unsigned)ego_cm >= NC) | (alt_talks && (unsigned)alt_cm >= NC);
+    const int c0 = (ego_talks && (unsigned)ego_cm < NC) ? ego_cm : -1;
+    const int c1 = (alt_talks && (unsigned)alt_cm < NC) ? alt_cm : -1;
     cm.st(0, c0);
     cm.st(1, c1);
-    // NAV_ACTIONS lookup + CAN_MOVE gating + ego_agent_idx (:248-262)
-    const int em = (p.cfg.can_move_mask & 1) ? (ego_mv & 3) : OC_ACT_NOOP;
-    const int am = (p.cfg.can_move_mask & 2) ? (alt_mv & 3) : OC_ACT_NOOP;
+    // NAV_ACTIONS lookup (both indices, moved or not: :248) + CAN_MOVE gating + ego_agent_idx
+    // (:250-262); NAV_ACTIONS[idx] raises for idx > 3: flagged, executed as (0, 0)
+    const bool bad_mv = ((unsigned)ego_mv > 3u) | ((unsigned)alt_mv > 3u);
+    const int em = ((p.cfg.can_move_mask & 1) && (unsigned)ego_mv <= 3u) ? ego_mv : OC_ACT_NOOP;
+    const int am = ((p.cfg.can_move_mask & 2) && (unsigned)alt_mv <= 3u) ? alt_mv : OC_ACT_NOOP;
     int act[A];
     act[0] = p.cfg.ego_agent_idx == 0 ? em : am;
     act[1] = p.cfg.ego_agent_idx == 0 ? am : em;
     const int err_before = e.err;
+    e.err |= (bad_mv | bad_cm) ? OC_ERR_ACTION : 0;
     ShapeIn<2> sin;
     ShapeLoads<2> sld;
     env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
@@ -1273,7 +1317,12 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     // ... and they drain while the shaping is summed
     double s0, s1;
     shaping_sum<2>(L, sin, sq, s0, s1 OC_STAMP_PASS);
-    Out(p.reward, p.n, 1, i, 8).st_f64(0, ((double)reward - s0) - s1);  // :282
+    const double shaped = ((double)reward - s0) - s1;  // :282
+    Out(p.reward, p.n, 1, i, 8).st_f64(0, shaped);
+    if (p.ep_return != nullptr) {   // uniform
+      Out(p.ep_return, p.n, 1, i, 8).st_f64(0, prev_done ? shaped : ep_ret + shaped);
+      Out(p.ep_length, p.n, 1, i).st(0, prev_done ? 1 : ep_len + 1);
+    }
   }
   OC_STAMP(7);   // every store issued
   slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
@@ -1675,11 +1724,13 @@ int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, cons
   }
 }
 
-int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int8_t *out, int8_t *holding,
+int32_t oc_image_words(const oc_level_t *lv) { return lv ? (7 * lv->hdr.ncells + 3) / 4 : 0; }
+
+int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int32_t *out, int8_t *holding,
                  int64_t n, void *stream) {
   if (lv && n == 0) return OC_OK;
   if (!lv || !state || !out || !holding || n < 0) return fail(OC_E_BADARG, "oc_obs_image: bad argument");
-  if (!fits_buffer(n, 2 * 7 * lv->hdr.ncells, 1))
+  if (!fits_buffer(n, 2 * oc_image_words(lv), 4))
     return fail(OC_E_BADARG, "oc_obs_image: n too large for one call; split the batch");
   ImageArgs a{lv->hdr, state, out, holding, n, radius};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
@@ -1691,8 +1742,10 @@ int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int
 int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
                   const oc_wrap_cfg *cfg, void *obs, double *timestep, double *reward, int32_t *done,
                   int32_t *sparse, int32_t auto_reset, int64_t *metrics, const int32_t *placement, uint32_t *rng,
-                  int64_t n, void *stream) {
+                  double *ep_return, int32_t *ep_length, int64_t n, void *stream) {
   if (lv && cfg && n == 0) return OC_OK;
+  if ((ep_return == nullptr) != (ep_length == nullptr))
+    return fail(OC_E_BADARG, "oc_multi_step: pass both ep_return and ep_length, or neither");
   if (!lv || !state || !comm || !actions || !cfg || !obs || !timestep || !reward || !done || n < 0 ||
       cfg->obs.num_comm < 0 || cfg->obs.num_comm > 128)
     return fail(OC_E_BADARG, "oc_multi_step: bad argument");
@@ -1703,7 +1756,7 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   if (auto_reset && lv->hdr.nscatter > 0 && !placement && !rng)
     return fail(OC_E_BADARG, "oc_multi_step: auto_reset on a random-placement level needs `placement` or `rng`");
   MultiArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, comm, actions, obs, timestep,
-              reward, done, sparse, metrics, placement, rng, n, auto_reset, *cfg};
+              reward, done, sparse, metrics, placement, rng, ep_return, ep_length, n, auto_reset, *cfg};
   const size_t lds = (size_t)lv->n16 * 16;
   const bool in_lds = tables_in_lds(n);
   const int ot = cfg->obs.obs_int8;   // 0 int32, 1 int8, 2 float32
@@ -1728,6 +1781,19 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   return fail(OC_E_BADARG, "oc_multi_step: unsupported number of items");
 #endif
 #undef OC_MS
+}
+
+int oc_random_actions(uint32_t *rng, int32_t *move_row, int32_t *comm_row, int32_t num_comm, int64_t n,
+                      void *stream) {
+  if (n == 0 && rng && move_row && comm_row) return OC_OK;
+  if (!rng || !move_row || !comm_row || n < 0 || num_comm < 1)
+    return fail(OC_E_BADARG, "oc_random_actions: bad argument");
+  const int bs = 256;
+  hipLaunchKernelGGL(k_random_actions, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, (hipStream_t)stream, rng,
+                     move_row, comm_row, (uint32_t)num_comm, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "kernel launch");
+  return OC_OK;
 }
 
 }  // extern "C"

@@ -55,5 +55,18 @@ def gather_rollout_metrics(local: torch.Tensor, elapsed_s: float, group=None) ->
     return {"per_rank": per_rank, "total": total, "elapsed_s": el}
 
 
+def reduce_max(values, device=None, group=None):
+    """MAX over ranks of a short list of floats (the values themselves when no process group
+    is up).  `device`: where the exchanged tensor lives (a CUDA device for backend nccl/RCCL,
+    None = host for gloo)."""
+    import torch.distributed as dist
+    vals = [float(v) for v in values]
+    if not (dist.is_available() and dist.is_initialized()):
+        return vals
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.cpu().tolist()
+
+
 def whole_job_rate(total_env_steps: int, elapsed_s: float) -> float:
     return float(total_env_steps) / float(elapsed_s)

@@ -93,10 +93,20 @@ class OvercookedEnvironment:
     step({"agent-i": (dx, dy)}) -> (reward: int, done: bool, info: dict)."""
 
     def __init__(self, arglist, device="cuda", subtask_order=None, placements=None,
-                 level_dir=None, _batch=None):
+                 level_dir=None, _batch=None, _index=0, _view=False):
+        """``_batch`` / ``_index`` / ``_view``: bind to env ``_index`` of an existing
+        ``BatchedOvercooked`` instead of creating a 1-env batch; with ``_view`` the object is a
+        read-only mirror of that env (what ``EpisodeRecorder`` / ``ParallelEpisodeRecorder`` read:
+        ``t``, ``world``, ``sim_agents``, ``completed_subtasks``, ``display()``, ``str()``,
+        episode_recorder.py:15-85) and the batch is stepped by its owner."""
         self.arglist = arglist
+        if _arg(arglist, "play", False):
+            # interact() takes other branches with arglist.play (merges onto the counter, chops on
+            # pick-up: utils/interact.py:44-47,52,66-67); that interactive mode is not built
+            raise ValueError("arglist.play=True (interactive play mode) is not supported")
         ego = dict(_arg(arglist, "ego_config", {}) or {})
         partner = dict(_arg(arglist, "partner_config", {}) or {})
+        self._index, self._view = int(_index), bool(_view)
         self._b = _batch or BatchedOvercooked(
             _arg(arglist, "level"), num_agents=_arg(arglist, "num_agents"), num_envs=1,
             max_num_timesteps=_arg(arglist, "max_num_timesteps", 100),
@@ -111,6 +121,7 @@ class OvercookedEnvironment:
         self._stale, self._pending_words = False, None
         self._v_world = SimpleNamespace(width=lv.width, height=lv.height,
                                         perimeter=2 * (lv.width + lv.height), arglist=arglist)
+        self._v_world.get_object_list = lambda: list(self._v_world.objects_in_order)
         self.recipes = list(lv.recipes)
         self.all_subtasks = [s.name for s in lv.subtasks]
         self._v_sim_agents = [_SimAgent(i, self._b.ego_config if i == 0 else self._b.partner_config)
@@ -119,8 +130,16 @@ class OvercookedEnvironment:
         self.successful = False
         self.collisions = []
         self.agent_actions = {}
-        self._act = torch.zeros((lv.num_agents, 1), dtype=torch.int32, device=self._b.device)
-        self.reset()
+        if self._view:
+            self._stale = True              # materialised from the device on first read
+        else:
+            self._act = torch.zeros((lv.num_agents, 1), dtype=torch.int32, device=self._b.device)
+            self.reset()
+
+    def mark_dirty(self):
+        """The batch has moved on: rebuild the mirror from the device at the next read."""
+        self._pending_words = None
+        self._stale = True
 
     # -- state mirror ------------------------------------------------------------
     # The reference's attributes (t, completed_subtasks, goal_objects_count, world, sim_agents,
@@ -152,8 +171,10 @@ class OvercookedEnvironment:
         from .state import unpack_state
         lv = self._b.level
         self._stale = False
-        s = self._b.snapshot() if words is None else unpack_state(words, lv.num_agents, lv.num_items,
-                                                                  lv.num_subtasks)
+        if words is None:                   # one column of the [A+M+2][n] state tensor
+            i = self._index
+            words = self._b.state[:, i:i + 1].cpu().numpy()
+        s = unpack_state(words, lv.num_agents, lv.num_items, lv.num_subtasks)
         self._v_t = int(s["t"][0])
         self._v_completed_subtasks = [int(v) for v in s["completed"][0]]
         self._v_goal_objects_count = [int(v) for v in s["goal_count"][0]]
@@ -166,6 +187,9 @@ class OvercookedEnvironment:
             contents = [_Content(lv.items[i][0], int(items[i][2])) for i in members]
             objs[int(g)] = _Object(contents, (int(items[g][0]), int(items[g][1])), items[g][4] >= 0)
         self._v_world.objects_in_order = [objs[int(g)] for g in order if g >= 0]
+        self._v_world.objects = {}          # name -> list, as World.objects (utils/world.py:21), movable objects only
+        for o in self._v_world.objects_in_order:
+            self._v_world.objects.setdefault(o.name, []).append(o)
         for a, ag in enumerate(self._v_sim_agents):
             ag.location = (int(agents[a][0]), int(agents[a][1]))
             ag.holding = objs.get(int(agents[a][2])) if agents[a][2] >= 0 else None
@@ -327,6 +351,8 @@ class OvercookedEnvironment:
 
     # -- API ---------------------------------------------------------------------
     def reset(self):
+        if self._view:
+            raise RuntimeError("this is a view of env %d of a batch; reset the batch" % self._index)
         self._b.reset()
         self.termination_info = ""
         self.successful = False
@@ -334,6 +360,8 @@ class OvercookedEnvironment:
         self._sync()
 
     def step(self, action_dict):
+        if self._view:
+            raise RuntimeError("this is a view of env %d of a batch; step the batch" % self._index)
         for a, ag in enumerate(self.sim_agents):
             act = tuple(int(v) for v in action_dict[ag.name])        # KeyError like the reference (:217)
             if act not in _CODE_OF:

@@ -28,6 +28,25 @@ SPEC_DIR = os.path.join(_build.CSRC, "_spec")
 _I32P = ctypes.POINTER(ctypes.c_int32)
 
 
+_PROFILER_VARS = ("ROCP_", "ROCPROF", "ROCTRACER", "HSA_TOOLS_LIB", "ROCPROFILER")
+
+
+def profiler_attached() -> bool:
+    """True when this process runs under rocprofv3 / rocprof (their tool library is preloaded
+    or injected through HSA_TOOLS_LIB)."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    if "rocprof" in pre or "roctracer" in pre:
+        return True
+    return any(k.startswith(_PROFILER_VARS) for k in os.environ)
+
+
+def clean_env():
+    """Environment for the hipcc child chain: nothing of a profiler's injection survives."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith(_PROFILER_VARS)}
+    env.pop("LD_PRELOAD", None)
+    return env
+
+
 def spec_header_text(blob) -> str:
     """The generated header for a level blob (host only, no GPU needed)."""
     L = _lib.load()
@@ -71,6 +90,12 @@ def ensure(blob, verbose=False):
     path = os.path.join(SPEC_DIR, "liboc_spec_%s.so" % key)
     if os.path.exists(path):
         return path
+    if profiler_attached():
+        # hipcc execs clang and lld; under rocprofv3 this process has already initialised the
+        # GPU (the profiler's preloaded library does) and those exec hops would inherit its
+        # LD_PRELOAD -- the pattern that takes this pool's machines down.  Never JIT here: the
+        # caller falls back to the generic library (or fails, with mode=True).
+        return None
     try:
         hipcc = _build.hipcc_path()
     except RuntimeError:
@@ -90,7 +115,7 @@ def ensure(blob, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     try:
-        subprocess.check_call(cmd)
+        subprocess.check_call(cmd, env=clean_env())
         os.replace(tmp_lib, path)
     finally:
         if os.path.exists(tmp_lib):

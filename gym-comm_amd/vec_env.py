@@ -10,24 +10,41 @@ ego/partner protocol runs on tensors:
     obs_ego = venv.reset()
     obs_ego, rewards, dones, infos = venv.step(ego_actions)      # ego_actions [n, 2] = (move, comm)
 
-Every ``step`` asks ``partner(obs_partner)`` for the partner's [n, 2] actions on the
-observations it saw after the previous step (SimultaneousEnv semantics,
-multiagentenv.py:395-404), calls the fused ``oc_multi_step`` kernel once, and reports
-``partner.update(rewards, dones)`` if the partner has that method.  Finished envs are
-auto-reset inside the kernel, so -- as with any SB3 VecEnv -- the observation returned for
-a done env is the first observation of its next episode and ``rewards``/``dones`` belong to
+Call order of one step, as ``MultiAgentEnv.step`` (multiagentenv.py:149-215):
+``partner.act_into(obs_partner)`` on the observations the partner saw after the previous step
+(``_get_actions``: ``agent.get_action(ob)``, SimultaneousEnv semantics :395-404); the fused
+``oc_multi_step`` kernel once (``n_step``); ``partner.update(rewards, dones)`` if the partner
+has that method (``_update_players`` -> ``OnPolicyAgent.update``, agents.py:168-185).  Finished
+envs are auto-reset inside the kernel, so -- as with any SB3 VecEnv -- the observation returned
+for a done env is the first observation of its next episode and ``rewards``/``dones`` belong to
 the finished step.  ``infos[i]["terminal_observation"]`` is only filled with
-``terminal_obs=True`` (three launches per step instead of one).
+``terminal_obs=True`` (three launches per step instead of one).  Episode return / length
+(what SB3's ``Monitor`` adds: ``infos[i]["episode"]``) are kept by the kernel itself.
+
+Partners
+  ``RandomPartner``        uniform random, one launch of the library's own generator kernel;
+  ``TorchPolicyPartner``   any ``torch.nn.Module`` mapping the observation dict to (move logits,
+                           comm logits) -- the batched stand-in for pantheonrl's
+                           ``OnPolicyAgent.get_action`` / ``update`` (agents.py:112-194);
+  any callable ``partner(obs_dict) -> [n, 2]`` still works (slow path).
+
+``ClosedLoop`` (``venv.closed_loop(ego)``) captures ego policy -> partner policy -> fused step
+(+ in-kernel episode statistics) in one hipGraph, so a rollout costs one graph replay per step
+(or per k steps) instead of a dozen host-side launches.
 
 Subclasses ``stable_baselines3.common.vec_env.VecEnv`` when SB3 is importable; otherwise a
 structural stand-in with the same methods.  ``step_tensors`` is the zero-copy variant for
 policies that live on the GPU.
 """
+import ctypes
+import os
+
 import numpy as np
 import torch
 
-from .batched import BatchedOvercooked
-from .envs import _arg, make_spaces
+from . import _lib
+from .batched import BatchedOvercooked, OBS_KEYS
+from .envs import OvercookedEnvironment, _arg, make_spaces
 
 try:                                                    # pragma: no cover - SB3 absent in CI image
     from stable_baselines3.common.vec_env import VecEnv as _VecEnvBase
@@ -53,33 +70,204 @@ SPACE_DTYPE = {
 }
 
 
+class ObsView(dict):
+    """One viewer's observation: the 11 keys of get_observation2 as [n, k] tensor views, plus
+    the storage they are views of -- ``rows`` ([F][n], the kernel's env-major rows; a policy
+    that consumes them feature-major needs no gather, transpose or concat) and ``timestep``
+    (f64 [n]).  The same objects every step; the next step overwrites their contents."""
+    rows = None
+    timestep = None
+
+
 class RandomPartner:
-    """Uniform random partner (move 0..3, comm 0..C-1), generated on the device."""
+    """Uniform random partner (move 0..3, comm 0..C-1): one launch of ``oc_random_actions``
+    (a PCG32 stream per env), written straight into the kernel's action rows."""
+    graph_safe = True
 
     def __init__(self, num_comm, seed=0, device="cuda"):
-        self.C = num_comm
-        self.gen = torch.Generator(device=device).manual_seed(seed)
-        self.device = device
+        self.C = int(num_comm)
+        self.seed = int(seed)
+        self.device = torch.device(device)
+        self._L = _lib.load()
+        self._rng = None
+
+    def _state(self, n):
+        if self._rng is None or self._rng.numel() != n:
+            g = torch.Generator(device="cpu").manual_seed(self.seed)
+            self._rng = torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64
+                                      ).to(torch.int32).to(self.device)
+        return self._rng
+
+    def act_into(self, obs, move_row, comm_row):
+        n = move_row.numel()
+        dev = move_row.device.index
+        if torch.cuda.current_device() != dev:
+            with torch.cuda.device(dev):
+                return self.act_into(obs, move_row, comm_row)
+        rc = self._L.oc_random_actions(self._state(n).data_ptr(), move_row.data_ptr(), comm_row.data_ptr(),
+                                       self.C, n, torch._C._cuda_getCurrentRawStream(dev))
+        if rc:
+            _lib.check(rc, "oc_random_actions", self._L)
+
+    def get_state(self, n):
+        """A copy of the generator state for n envs (allocated on first use)."""
+        return self._state(n).clone()
+
+    def set_state(self, st):
+        self._state(st.numel()).copy_(st)
 
     def __call__(self, obs):
         n = next(iter(obs.values())).shape[0]
-        mv = torch.randint(0, 4, (n,), generator=self.gen, device=self.device, dtype=torch.int32)
-        cm = torch.randint(0, self.C, (n,), generator=self.gen, device=self.device, dtype=torch.int32)
-        return torch.stack([mv, cm], dim=1)
+        out = torch.empty((2, n), dtype=torch.int32, device=self.device)
+        self.act_into(obs, out[0], out[1])
+        return out.T
 
+
+class MLPPolicy(torch.nn.Module):
+    """A small two-layer policy over get_observation2's 22 + S + 2C features (+ timestep):
+    returns (move logits [4][n], comm logits [C][n]).  Feature-major on purpose: the kernel
+    leaves a viewer's observation as [F][n] rows in HBM (float32 with ``obs_dtype=float32``), so
+    the first layer is one GEMM on those rows as they lie -- no gather, no transpose, no concat.
+    An observation dict without ``rows`` (any other env) is concatenated the slow way."""
+    feature_major = True
+
+    def __init__(self, num_subtasks, num_comm, hidden=64, seed=0):
+        super().__init__()
+        F = 22 + int(num_subtasks) + 2 * int(num_comm)
+        g = torch.Generator().manual_seed(int(seed))
+        init = lambda *shape: torch.nn.Parameter(
+            (torch.rand(shape, generator=g) * 2 - 1) / float(np.sqrt(shape[-1])))
+        self.w1, self.b1, self.wt = init(hidden, F), init(hidden, 1), init(hidden, 1)
+        self.w2, self.b2 = init(4 + int(num_comm), hidden), init(4 + int(num_comm), 1)
+        self.C = int(num_comm)
+
+    def forward(self, obs):
+        rows = getattr(obs, "rows", None)
+        if rows is None:
+            rows = torch.cat([obs[k].reshape(obs[k].shape[0], -1) for k in OBS_KEYS], dim=1).T
+            ts = obs["timestep"].reshape(1, -1)
+        else:
+            ts = obs.timestep.unsqueeze(0)
+        if rows.dtype != torch.float32:
+            rows = rows.to(torch.float32)
+        h = torch.addmm(self.b1, self.w1, rows)                 # [H][n]
+        h = torch.addcmul(h, self.wt, ts.to(torch.float32))
+        out = torch.addmm(self.b2, self.w2, torch.tanh_(h))     # [4 + C][n]
+        return out[:4], out[4:]
+
+
+class TorchPolicyPartner:
+    """A torch module in the partner (or ego) seat.  ``policy(obs) -> (move_logits,
+    comm_logits)``, each [n, k] -- or [k, n] when ``policy.feature_major`` is true.  Actions are
+    the argmax (``sample=False``) or a categorical sample (Gumbel-max on the default CUDA
+    generator, so the draw is hipGraph-capturable), written straight into the kernel's action
+    rows.  ``update(rewards, dones)`` -- pantheonrl's ``Agent.update`` -- is forwarded to
+    ``on_update`` (e.g. a rollout buffer's add), called after every step."""
+
+    def __init__(self, policy, sample=True, seed=None, device="cuda", on_update=None):
+        self.policy = policy
+        self.sample = bool(sample)
+        self.device = torch.device(device)
+        self.on_update = on_update
+        # stateless between steps and fixed-shape => one capture serves every later step
+        self.graph_safe = on_update is None
+        if seed is not None:
+            with torch.cuda.device(self.device):
+                torch.cuda.manual_seed(int(seed))
+
+    def _pick(self, logits, dim):
+        if self.sample:     # argmax(logits - log E), E ~ Exp(1)  ==  a categorical sample
+            logits = logits - torch.empty_like(logits).exponential_().log_()
+        return logits.argmax(dim=dim)
+
+    @torch.no_grad()
     def act_into(self, obs, move_row, comm_row):
-        """Same draw, written straight into the kernel's action rows (int32 [n] each): two
-        launches instead of four (no stack, no transpose-copy)."""
-        move_row.random_(0, 4, generator=self.gen)
-        comm_row.random_(0, self.C, generator=self.gen)
+        mv, cm = self.policy(obs)
+        dim = 0 if getattr(self.policy, "feature_major", False) else 1
+        move_row.copy_(self._pick(mv, dim))
+        comm_row.copy_(self._pick(cm, dim))
+
+    def __call__(self, obs):
+        n = next(iter(obs.values())).shape[0]
+        out = torch.empty((2, n), dtype=torch.int32, device=self.device)
+        self.act_into(obs, out[0], out[1])
+        return out.T
+
+    def update(self, rewards, dones):
+        if self.on_update is not None:
+            self.on_update(rewards, dones)
+
+
+class ClosedLoop:
+    """ego policy -> partner policy -> fused step, ``steps`` times, as ONE hipGraph.
+
+    ``ego``: something with ``act_into(obs, move_row, comm_row)`` (``TorchPolicyPartner``,
+    ``RandomPartner``), or None -- then the caller writes the ego's (move, comm) into
+    ``venv.ego_action_rows`` before every ``step()``.  ``enqueue()`` issues the launches of one
+    step eagerly (what gets captured; also usable inside a caller's own capture)."""
+
+    def __init__(self, venv, ego=None, graph=True, steps=1):
+        self.venv, self.ego, self.steps = venv, ego, int(steps)
+        self.graph = None
+        if graph:
+            for pl in (ego, venv.partner):
+                if pl is not None and not getattr(pl, "graph_safe", False):
+                    raise ValueError("%r is not marked graph_safe (stateless, fixed-shape)" % (pl,))
+            b = venv._b
+            # one eager warm-up step (module loads, rocBLAS workspaces) that must not count: the
+            # env's tensors, the action rows and every random stream are put back afterwards
+            players = [pl for pl in (ego, venv.partner) if pl is not None]
+            keep, act = b._arena.clone(), venv._act.clone()
+            rng = None if b.rng is None else b.rng.clone()
+            torch_rng = torch.cuda.get_rng_state(b.device)
+            saved = [pl.get_state(venv.num_envs) if hasattr(pl, "get_state") else None for pl in players]
+            ver = venv._version
+            self.enqueue()
+            torch.cuda.current_stream(b.device).synchronize()
+            b._arena.copy_(keep)
+            venv._act.copy_(act)
+            if rng is not None:
+                b.rng.copy_(rng)
+            torch.cuda.set_rng_state(torch_rng, b.device)
+            for pl, st in zip(players, saved):
+                if hasattr(pl, "set_state"):
+                    pl.set_state(st)
+            venv._version = ver
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                for _ in range(self.steps):
+                    self.enqueue()
+            venv._version = ver
+
+    def enqueue(self):
+        v = self.venv
+        if self.ego is not None:
+            self.ego.act_into(v._obs_tensors(0), v._act[0], v._act[1])
+        v.partner.act_into(v._obs_tensors(1), v._act[2], v._act[3])
+        v._b.multi_step(v._act)
+        v._version += 1
+
+    def step(self):
+        """Returns (ego obs, shaped reward f64 [n], done int32 [n]) -- views of the tensors the
+        next step overwrites."""
+        v = self.venv
+        if self.graph is not None:
+            self.graph.replay()
+            v._version += self.steps
+        else:
+            for _ in range(self.steps):
+                self.enqueue()
+        return v._obs_tensors(0), v._b.shaped_reward, v._b.done
 
 
 class OvercookedVecEnv(_VecEnvBase):
     def __init__(self, arglist, num_envs, partner=None, device="cuda", terminal_obs=False,
                  ego_agent_idx=0, subtask_order=None, level_dir=None, seed=0,
-                 track_episode_stats=True, **batched_kw):
+                 track_episode_stats=True, use_graph=False, **batched_kw):
         if _arg(arglist, "num_agents") != 2:
             raise ValueError("the gym_comm wrapper drives exactly 2 agents")
+        if _arg(arglist, "play", False):
+            raise ValueError("arglist.play=True (interactive play mode) is not supported")
         self.arglist = arglist
         self.terminal_obs = bool(terminal_obs)
         self.track_episode_stats = bool(track_episode_stats)
@@ -93,22 +281,39 @@ class OvercookedVecEnv(_VecEnvBase):
             communication_on=_arg(arglist, "communication_on", False),
             ego_led=_arg(arglist, "ego_led", False), fow_radius=_arg(arglist, "fow_radius", 2),
             ego_agent_idx=ego_agent_idx, device=device, subtask_order=subtask_order,
-            level_dir=level_dir, auto_reset=True, seed=seed, **batched_kw)
+            level_dir=level_dir, auto_reset=True, seed=seed,
+            episode_stats=self.track_episode_stats, **batched_kw)
         lv = self._b.level
         obs_space, act_space = make_spaces(lv.width, lv.height, lv.num_subtasks, self._b.C)
         super().__init__(num_envs, obs_space, act_space)
         self.partner = partner if partner is not None else RandomPartner(self._b.C, seed, self._b.device)
         self._act = torch.zeros((4, num_envs), dtype=torch.int32, device=self._b.device)
         self._pending = None
-        self._partner_obs = None
         # the kernel overwrites the same observation rows every step, so the 11-key views of
         # both viewers are built once (22 slice + transpose objects cost ~60 us per step otherwise)
         self._views = [None, None]
         self._infos = [{} for _ in range(num_envs)]      # reused; only finished envs are touched
         self._dirty = []
         self._dtype_groups = None
-        self.episode_returns = torch.zeros(num_envs, dtype=torch.float64, device=self._b.device)
-        self.episode_lengths = torch.zeros(num_envs, dtype=torch.int64, device=self._b.device)
+        self._last_terminal = None
+        self._version = 0                                # bumped by every step / reset
+        self._env_views = {}                             # env index -> (OvercookedEnvironment view, version)
+        self._use_graph = bool(use_graph) and not self.terminal_obs
+        self._loop = None
+
+    # the running episode statistics live in the batch (kept by the kernel)
+    @property
+    def episode_returns(self):
+        return self._b.ep_return
+
+    @property
+    def episode_lengths(self):
+        return self._b.ep_length
+
+    @property
+    def ego_action_rows(self):
+        """int32 [2][n]: the ego's (move, comm) rows of the kernel's action tensor."""
+        return self._act[0:2]
 
     # -- tensors ---------------------------------------------------------------------
     def _obs_tensors(self, viewer):
@@ -116,45 +321,58 @@ class OvercookedVecEnv(_VecEnvBase):
         tensor objects every step -- the next step overwrites their contents)."""
         if self._views[viewer] is None:
             d = self._b.obs_dict(viewer)
-            self._views[viewer] = {k: v.T for k, v in d.items()}
+            v = ObsView((k, t.T) for k, t in d.items())
+            v.rows, v.timestep = self._b.obs[viewer], self._b.timestep
+            self._views[viewer] = v
         return self._views[viewer]
 
     def reset_tensors(self):
-        self._b.reset()
-        self._b.observe()
-        self.episode_returns.zero_()
-        self.episode_lengths.zero_()
-        self._partner_obs = self._obs_tensors(1)
+        b = self._b
+        b.reset()
+        b.done.zero_()
+        if self.track_episode_stats:
+            b.ep_return.zero_()
+            b.ep_length.zero_()
+        b.observe()
+        self._version += 1
         return self._obs_tensors(0)
 
-    def step_tensors(self, ego_actions):
-        """ego_actions: int tensor [n, 2] on the device.  Returns (ego obs dict of [n, k]
-        tensors, shaped reward f64 [n], done int32 [n]) -- views that the next step
-        overwrites."""
+    def closed_loop(self, ego=None, graph=True, steps=1):
+        """ego policy -> partner policy -> fused step as one hipGraph (see ``ClosedLoop``)."""
+        return ClosedLoop(self, ego, graph=graph, steps=steps)
+
+    def step_tensors(self, ego_actions=None):
+        """ego_actions: int tensor [n, 2] on the device (None: already written into
+        ``ego_action_rows``).  Returns (ego obs dict of [n, k] tensors, shaped reward f64 [n],
+        done int32 [n]) -- views that the next step overwrites."""
         b = self._b
-        # rows of the action tensor: ego move, ego comm, alt move, alt comm
-        if hasattr(self.partner, "act_into"):
-            self.partner.act_into(self._partner_obs, self._act[2], self._act[3])
-        else:
-            pa = torch.as_tensor(self.partner(self._partner_obs), device=b.device)
-            self._act[2:4].copy_(pa.T)
-        self._act[0:2].copy_(torch.as_tensor(ego_actions, device=b.device).T)
+        if ego_actions is not None:
+            self._act[0:2].copy_(torch.as_tensor(ego_actions, device=b.device).T)
+        partner_obs = self._obs_tensors(1)
         term = None
-        if self.terminal_obs:
-            b.multi_step(self._act, auto_reset=False)
-            term = {k: v.clone() for k, v in self._obs_tensors(0).items()}
-            b.reset(b.done)                                   # mask = done flags
-            b.observe()
+        if self._use_graph:
+            if self._loop is None:          # partner -> fused step, captured once
+                self._loop = ClosedLoop(self, None, graph=True)
+            self._loop.step()
         else:
-            b.multi_step(self._act)
+            # rows of the action tensor: ego move, ego comm, alt move, alt comm
+            if hasattr(self.partner, "act_into"):
+                self.partner.act_into(partner_obs, self._act[2], self._act[3])
+            else:
+                pa = torch.as_tensor(self.partner(partner_obs), device=b.device)
+                self._act[2:4].copy_(pa.T)
+            if self.terminal_obs:
+                b.multi_step(self._act, auto_reset=False)
+                term = {k: v.clone() for k, v in self._obs_tensors(0).items()}
+                b.reset(b.done)                                   # mask = done flags
+                b.observe()
+            else:
+                b.multi_step(self._act)
+            self._version += 1
         rew, done = b.shaped_reward, b.done
-        if self.track_episode_stats:
-            self.episode_returns += rew
-            self.episode_lengths += 1
         self._last_terminal = term
         if hasattr(self.partner, "update"):
             self.partner.update(rew, done)
-        self._partner_obs = self._obs_tensors(1)
         return self._obs_tensors(0), rew, done
 
     # -- SB3 VecEnv API (numpy) --------------------------------------------------------
@@ -241,16 +459,16 @@ class OvercookedVecEnv(_VecEnvBase):
         idx = np.nonzero(done_np)[0]
         self._dirty = idx.tolist()
         if len(idx):
-            ret = self.episode_returns.cpu().numpy()
-            ln = self.episode_lengths.cpu().numpy()
             term = self._to_numpy(self._last_terminal) if self._last_terminal is not None else None
+            if self.track_episode_stats:
+                # after a step that returned done the kernel's rows hold the finished episode's totals
+                ret = self._b.ep_return.cpu().numpy()
+                ln = self._b.ep_length.cpu().numpy()
             for i in idx:
-                infos[i]["episode"] = {"r": float(ret[i]), "l": int(ln[i])}     # Monitor-style
+                if self.track_episode_stats:
+                    infos[i]["episode"] = {"r": float(ret[i]), "l": int(ln[i])}     # Monitor-style
                 if term is not None:
                     infos[i]["terminal_observation"] = {k: v[i] for k, v in term.items()}
-            m = done.bool()
-            self.episode_returns[m] = 0
-            self.episode_lengths[m] = 0
         return obs_np, rew_np, done_np, list(infos)   # shallow copy: holders keep their dicts
 
     def close(self):
@@ -259,20 +477,120 @@ class OvercookedVecEnv(_VecEnvBase):
     def seed(self, seed=None):
         return [seed] * self.num_envs
 
+    # -- per-env access (VecEnv.get_attr / env_method) -------------------
+    # ParallelEpisodeRecorder reads env.get_attr('t' | 'world' | 'sim_agents' | 'arglist', i)[0]
+    # and keeps the world / sim_agents objects between steps (episode_recorder.py:48-85), so the
+    # view of env i is ONE persistent object whose mirror is refreshed from the device -- a
+    # column of A+M+2 state words -- when it is read after the batch has moved on.
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        idx = [int(i) for i in np.atleast_1d(indices)]
+        for i in idx:
+            if not 0 <= i < self.num_envs:
+                raise IndexError("env index %d outside 0..%d" % (i, self.num_envs - 1))
+        return idx
+
+    def base_env(self, i):
+        """The ``OvercookedEnvironment``-shaped view of env i (read-only; ``t``, ``world``,
+        ``sim_agents``, ``completed_subtasks``, ``rep``, ``str()``, ``display()``,
+        ``render_frame()``)."""
+        i = self._indices([i])[0]
+        ent = self._env_views.get(i)
+        if ent is None:
+            ent = [OvercookedEnvironment(self.arglist, _batch=self._b, _index=i, _view=True), -1]
+            self._env_views[i] = ent
+        if ent[1] != self._version:
+            ent[0].mark_dirty()
+            ent[1] = self._version
+        return ent[0]
+
+    _PER_ENV_ATTRS = ("base_env", "t", "world", "sim_agents", "completed_subtasks", "goal_objects_count",
+                      "rep", "all_subtasks", "recipes")
+
     def get_attr(self, attr_name, indices=None):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [getattr(self, attr_name)] * n
+        idx = self._indices(indices)
+        if attr_name == "base_env":
+            return [self.base_env(i) for i in idx]
+        if attr_name in self._PER_ENV_ATTRS:
+            return [getattr(self.base_env(i), attr_name) for i in idx]
+        return [getattr(self, attr_name)] * len(idx)
 
     def set_attr(self, attr_name, value, indices=None):
         setattr(self, attr_name, value)
 
+    _PER_ENV_METHODS = ("render_frame", "render_rgb", "display", "get_agent_names", "__str__")
+
     def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [getattr(self, method_name)(*method_args, **method_kwargs)] * n
+        idx = self._indices(indices)
+        if method_name in self._PER_ENV_METHODS:
+            return [getattr(self.base_env(i), method_name)(*method_args, **method_kwargs) for i in idx]
+        return [getattr(self, method_name)(*method_args, **method_kwargs)] * len(idx)
 
     def env_is_wrapped(self, wrapper_class, indices=None):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [False] * n
+        return [False] * len(self._indices(indices))
 
     def metrics(self):
         return self._b.read_metrics()
+
+
+class BatchEpisodeRecorder:
+    """``ParallelEpisodeRecorder`` (episode_recorder.py:48-85) for the batched env: wraps an
+    ``OvercookedVecEnv``, counts episodes per env and, for the envs in ``indices`` whose episode
+    number is a multiple of ``record_interval``, collects one frame per step --
+    ``render_frame()`` of that env's view, i.e. the composition of the reference's pygame
+    renderer from device state (the ASCII ``str(env)`` without sprites).  A finished episode's
+    frames are handed to ``on_episode(env_index, episode, frames)`` (default: kept in
+    ``self.episodes``; ``save_dir`` writes them as .npz).  wandb / imageio / pygame are not
+    required."""
+
+    def __init__(self, venv, record_interval=-1, indices=(0,), sprite_dir=None, ascii_only=False,
+                 on_episode=None, save_dir=None):
+        self.env = venv
+        self.num_envs = venv.num_envs
+        self.record_interval = int(record_interval)
+        self.indices = [int(i) for i in indices]
+        self.episode_counts = {i: 0 for i in self.indices}
+        self.sprite_dir, self.ascii_only = sprite_dir, bool(ascii_only)
+        self.on_episode, self.save_dir = on_episode, save_dir
+        self._frames = {i: [] for i in self.indices}
+        self.episodes = []
+
+    def __getattr__(self, name):                   # gym.Wrapper-style pass-through
+        return getattr(self.env, name)
+
+    def _recording(self, i):
+        return self.record_interval > 0 and self.episode_counts[i] % self.record_interval == 0
+
+    def _frame(self, i):
+        v = self.env.base_env(i)
+        return str(v) if self.ascii_only else v.render_frame(self.sprite_dir)
+
+    def reset(self):
+        out = self.env.reset()
+        for i in self.indices:
+            self.episode_counts[i] += 1
+            self._frames[i] = [self._frame(i)] if self._recording(i) else []
+        return out
+
+    def step(self, actions):
+        obs, rew, dones, infos = self.env.step(actions)
+        for i in self.indices:
+            if dones[i]:
+                # the env was auto-reset inside the kernel: its view shows the first frame of the
+                # next episode, which starts that episode's recording
+                if self._frames[i]:
+                    ep = (i, self.episode_counts[i], self._frames[i])
+                    if self.on_episode is not None:
+                        self.on_episode(*ep)
+                    else:
+                        self.episodes.append(ep)
+                    if self.save_dir and not self.ascii_only:
+                        os.makedirs(self.save_dir, exist_ok=True)
+                        np.savez_compressed(os.path.join(self.save_dir, "env%d_ep%d.npz" % (i, ep[1])),
+                                            frames=np.stack(ep[2]))
+                self.episode_counts[i] += 1
+                self._frames[i] = []
+            if self._recording(i):
+                self._frames[i].append(self._frame(i))
+        return obs, rew, dones, infos

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 1
+#define OC_ABI_VERSION 2
 #define OC_API __attribute__((visibility("default")))
 
 enum {
@@ -95,7 +95,7 @@ enum {
   OC_MET_SUCCESSES = 2,     /* done because every delivery was made */
   OC_MET_REWARD_SUM = 3,    /* sum of the sparse integer reward */
   OC_MET_COMPLETED_SUM = 4, /* sum over finished episodes of completed subtasks */
-  OC_MET_ERRORS = 5,        /* env-steps that raised an OC_ERR_* flag */
+  OC_MET_ERRORS = 5,        /* env-steps that raised an OC_ERR_* flag (include/oc_level.h) */
   OC_MET_COUNT = 8
 };
 
@@ -159,9 +159,12 @@ OC_API int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *com
 
 /* OvercookedMultiEnv.get_partial_observability_FOW for both viewers
  * (gym_comm/envs/overcooked_env.py:161-202), the image-style fog-of-war observation.
- *   out      int8 [2][7*W*H][n]  row (k*W + x)*H + y = plane k at cell (x, y); -1 = fogged
- *   holding  int8 [2][n]         (agent 0 holds, agent 1 holds) */
-OC_API int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int8_t *out,
+ * Row r = (k*W + x)*H + y of a viewer = plane k at cell (x, y), int8, -1 = fogged; four
+ * consecutive rows of one env travel in one dword:
+ *   out      int32 [2][oc_image_words()][n]  byte b of word q = row 4q + b (zero past 7*W*H)
+ *   holding  int8 [2][n]                     (agent 0 holds, agent 1 holds) */
+OC_API int32_t oc_image_words(const oc_level_t *lv);                 /* ceil(7*W*H / 4) */
+OC_API int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int32_t *out,
                         int8_t *holding, int64_t n, void *stream);
 
 /* OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282) in ONE
@@ -171,11 +174,27 @@ OC_API int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radi
  *   actions  int32 [4][n]  ego move (0..3), ego comm, alt move, alt comm
  *   comm     int32 [2][n]  in/out, persists across resets (:89-91,284-297)
  *   reward   double[n]     shaped reward, identical for both agents
- *   sparse   int32 [n] or NULL  the unshaped integer reward */
+ *   sparse   int32 [n] or NULL  the unshaped integer reward
+ *   ep_return double[n], ep_length int32[n] (both or neither; NULL = off): per-env episode
+ *            statistics kept by the kernel, what stable-baselines3's Monitor keeps around the
+ *            reference's env (trainer.py:87-121 -> info["episode"] = {"r", "l"}): an env whose
+ *            `done` row was set by the PREVIOUS step starts from zero, then the step's shaped
+ *            reward / 1 is added.  After a step that returns done, ep_return / ep_length hold the
+ *            finished episode's return and length until the next step.  `done` must therefore be
+ *            the same tensor from step to step (zero it together with the statistics). */
 OC_API int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
                   const oc_wrap_cfg *cfg, void *obs, double *timestep, double *reward,
                   int32_t *done, int32_t *sparse, int32_t auto_reset, int64_t *metrics,
-                  const int32_t *placement, uint32_t *rng, int64_t n, void *stream);
+                  const int32_t *placement, uint32_t *rng, double *ep_return, int32_t *ep_length,
+                  int64_t n, void *stream);
+
+/* Uniform random (move, comm) indices for one player of every env, written straight into two
+ * rows of the [4][n] action tensor: move in 0..3, comm in 0..num_comm-1, from the env's own
+ * PCG32 stream (`rng`, uint32 [n], advanced in place).  No reference analogue -- the
+ * reference's partners are SB3 policies (pantheonrl/common/agents.py:60-194); this is the
+ * cheapest partner for throughput runs, one launch instead of two torch generator ops. */
+OC_API int oc_random_actions(uint32_t *rng, int32_t *move_row, int32_t *comm_row, int32_t num_comm,
+                             int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

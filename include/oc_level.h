@@ -72,8 +72,14 @@ enum { OC_ACT_DOWN = 0, OC_ACT_UP = 1, OC_ACT_LEFT = 2, OC_ACT_RIGHT = 3, OC_ACT
 enum {
   OC_ERR_OOB = 1,    /* an agent's proposed cell is outside the map: the reference's
                         get_gridsquare_at asserts (utils/world.py:310-315) */
-  OC_ERR_ALIAS = 2   /* World.remove() picked another agent's same-named object at the
+  OC_ERR_ALIAS = 2,  /* World.remove() picked another agent's same-named object at the
                         same cell (utils/world.py:239-247): only with >=3 agents overlapping */
+  OC_ERR_ACTION = 4  /* a move index outside 0..3 (base step: an action code outside 0..4) or, with
+                        communication on, a comm index outside 0..C-1: NAV_ACTIONS[idx] /
+                        one_hot[idx] raise IndexError in the reference
+                        (gym_comm/envs/overcooked_env.py:227-248).  The step treats the move as
+                        (0, 0) and the message as all zeros.  (Python would wrap -4..-1 / -C..-1;
+                        the batched path flags every negative index.) */
 };
 
 #endif

@@ -357,39 +357,159 @@ static int matches_goal(const Env *e, const Obj *o, const Sub *s) {
   return 1;
 }
 
-/* world.get_all_object_locs(obj=goal) (world.py:278-291): distinct locations of the
- * objects equal to the goal, held or not.  Returns count; first loc in (*x,*y). */
-static int goal_locs(const Env *e, const Sub *s, int *xs, int *ys) {
-  int lst[MAXOBJ * 2];
-  int n = world_list(e, lst), cnt = 0;
-  for (int i = 0; i < n; i++) {
-    const Obj *o = &e->objs[lst[i]];
-    if (!matches_goal(e, o, s)) continue;
-    int dup = 0;
-    for (int k = 0; k < cnt; k++)
-      if (xs[k] == o->x && ys[k] == o->y) dup = 1;
-    if (!dup) {
-      xs[cnt] = o->x;
-      ys[cnt] = o->y;
+/* ---- list(set(locations)) as CPython builds and iterates it -------------------------------
+ * World.get_all_object_locs returns list(set(held_locs + unheld_locs)) (world.py:290-291) and
+ * calculate_reward_shaping takes element [0] of it (overcooked_environment.py:287,374-379).
+ * With one matching object that is that object's location; with several (levels that repeat a
+ * content type) it is whichever location sits in the LOWEST SLOT of the set's hash table --
+ * deterministic (int and tuple hashes are not randomised), but neither world order nor
+ * sorted.  Restated here for CPython >= 3.8 (tuple hash: Objects/tupleobject.c, the
+ * xxHash-style tuplehash; set table: Objects/setobject.c, set_add_entry / set_table_resize /
+ * set_insert_clean with LINEAR_PROBES = 9, PERTURB_SHIFT = 5, an 8-slot table that grows 4x
+ * when fill * 5 >= mask * 3).  Pinned twice: against the running interpreter
+ * (tests/test_oracle_invariants.py, random location lists) and through the shaping bits of
+ * the tests/golden/c*_dup_* fixtures recorded from the reference. */
+static uint64_t py_hash_xy(int x, int y) { /* hash((x, y)) for small non-negative ints */
+  const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
+  uint64_t acc = P5;
+  const uint64_t lane[2] = {(uint64_t)x, (uint64_t)y}; /* hash(int) == int here */
+  for (int k = 0; k < 2; k++) {
+    acc += lane[k] * P2;
+    acc = (acc << 31) | (acc >> 33);
+    acc *= P1;
+  }
+  acc += 2ULL ^ (P5 ^ 3527539ULL);
+  if (acc == (uint64_t)-1) return 1546275796ULL;
+  return acc;
+}
+
+#define PYSET_MAX 64 /* table slots we ever need: <= 16 objects -> an 8-, 32- or 64-slot table */
+typedef struct {
+  int used, mask;
+  int key[PYSET_MAX]; /* x | y<<4, -1 = empty */
+  uint64_t hash[PYSET_MAX];
+} PySet;
+
+static void pyset_insert_clean(PySet *t, int key, uint64_t h) { /* set_insert_clean */
+  uint64_t perturb = h;
+  size_t i = (size_t)h & (size_t)t->mask;
+  for (;;) {
+    if (t->key[i] < 0) break;
+    if (i + 9 <= (size_t)t->mask) {
+      int found = 0;
+      for (size_t j = 1; j <= 9; j++)
+        if (t->key[i + j] < 0) {
+          i += j;
+          found = 1;
+          break;
+        }
+      if (found) break;
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & (size_t)t->mask;
+  }
+  t->key[i] = key;
+  t->hash[i] = h;
+}
+
+static void pyset_add(PySet *t, int x, int y) { /* set_add_entry; no deletions, so no dummies */
+  const int key = x | (y << 4);
+  const uint64_t h = py_hash_xy(x, y);
+  uint64_t perturb = h;
+  size_t i = (size_t)h & (size_t)t->mask;
+  for (;;) {
+    size_t probes = (i + 9 <= (size_t)t->mask) ? 9 : 0, j = i;
+    int placed = 0;
+    do {
+      if (t->key[j] < 0) {
+        t->key[j] = key;
+        t->hash[j] = h;
+        t->used++;
+        placed = 1;
+        break;
+      }
+      if (t->key[j] == key) return; /* already in the set */
+      j++;
+    } while (probes--);
+    if (placed) break;
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & (size_t)t->mask;
+  }
+  if (t->used * 5 >= t->mask * 3) { /* set_table_resize(so, used * 4) */
+    PySet old = *t;
+    int newsize = 8;
+    while (newsize <= old.used * 4) newsize <<= 1;
+    t->mask = newsize - 1;
+    for (int k = 0; k < PYSET_MAX; k++) t->key[k] = -1;
+    for (int k = 0; k <= old.mask; k++)
+      if (old.key[k] >= 0) pyset_insert_clean(t, old.key[k], old.hash[k]);
+  }
+}
+
+/* list(set(locs)): the distinct locations in the set's iteration order; returns the count */
+static int pyset_order(const int *xs, const int *ys, int n, int *ox, int *oy) {
+  PySet t;
+  t.used = 0;
+  t.mask = 7;
+  for (int k = 0; k < PYSET_MAX; k++) t.key[k] = -1;
+  for (int i = 0; i < n; i++) pyset_add(&t, xs[i], ys[i]);
+  int cnt = 0;
+  for (int k = 0; k <= t.mask; k++)
+    if (t.key[k] >= 0) {
+      ox[cnt] = t.key[k] & 15;
+      oy[cnt] = t.key[k] >> 4;
       cnt++;
     }
-  }
   return cnt;
 }
 
-/* location of the fresh X alone, for Chop(X) (start_obj of get_subtask_obj) */
-static int fresh_loc(const Env *e, int food, int *x, int *y) {
-  int lst[MAXOBJ * 2];
-  int n = world_list(e, lst);
-  for (int i = 0; i < n; i++) {
-    const Obj *o = &e->objs[lst[i]];
-    if (o->n == 1 && e->items[o->c[0]].type == food && e->items[o->c[0]].state == 0) {
-      *x = o->x;
-      *y = o->y;
-      return 1;
+/* exported for the test that pins the emulation against the running interpreter */
+__attribute__((visibility("default"))) int oc_oracle_pyset_order(const int32_t *xy, int n, int32_t *out_xy) {
+  int xs[MAXOBJ], ys[MAXOBJ], ox[MAXOBJ], oy[MAXOBJ];
+  if (n > MAXOBJ) n = MAXOBJ;
+  for (int i = 0; i < n; i++) xs[i] = xy[2 * i], ys[i] = xy[2 * i + 1];
+  int cnt = pyset_order(xs, ys, n, ox, oy);
+  for (int i = 0; i < cnt; i++) out_xy[2 * i] = ox[i], out_xy[2 * i + 1] = oy[i];
+  return cnt;
+}
+
+/* world.get_all_object_locs(obj) (world.py:278-291) for the objects `match` accepts:
+ * get_object_locs(is_held=True) + get_object_locs(is_held=False), each in the order of the
+ * name's list, then list(set(...)).  Returns the number of distinct locations, in CPython's
+ * set order (element [0] is what the shaping terms use). */
+typedef int (*MatchFn)(const Env *, const Obj *, const void *);
+static int all_object_locs(const Env *e, MatchFn match, const void *arg, int *xs, int *ys) {
+  int lst[MAXOBJ * 2], rx[MAXOBJ], ry[MAXOBJ];
+  int n = world_list(e, lst), m = 0;
+  for (int held = 1; held >= 0; held--)
+    for (int i = 0; i < n; i++) {
+      const Obj *o = &e->objs[lst[i]];
+      if (o->is_held == held && match(e, o, arg)) {
+        rx[m] = o->x;
+        ry[m] = o->y;
+        m++;
+      }
     }
-  }
-  return 0;
+  return pyset_order(rx, ry, m, xs, ys);
+}
+
+static int match_goal_fn(const Env *e, const Obj *o, const void *s) { return matches_goal(e, o, (const Sub *)s); }
+static int goal_locs(const Env *e, const Sub *s, int *xs, int *ys) {
+  return all_object_locs(e, match_goal_fn, s, xs, ys);
+}
+
+/* location of "the" fresh X alone, for Chop(X) (start_obj of get_subtask_obj;
+ * get_all_object_locs(obj=start_obj)[0], overcooked_environment.py:287) */
+static int match_fresh_fn(const Env *e, const Obj *o, const void *food) {
+  return o->n == 1 && e->items[o->c[0]].type == *(const int *)food && e->items[o->c[0]].state == 0;
+}
+static int fresh_loc(const Env *e, int food, int *x, int *y) {
+  int xs[MAXOBJ], ys[MAXOBJ];
+  int n = all_object_locs(e, match_fresh_fn, &food, xs, ys);
+  if (n == 0) return 0;
+  *x = xs[0];
+  *y = ys[0];
+  return 1;
 }
 
 /* done (overcooked_environment.py:243-270) */
@@ -590,7 +710,10 @@ OC_EXPORT void oc_oracle_step(void *h, const int32_t *actions, int32_t *reward, 
   e->t += 1;
   for (int a = 0; a < e->A; a++) {
     int c = actions[a];
-    if (c < 0 || c > 4) c = 4;
+    if (c < 0 || c > 4) { /* no such NAV action: flagged, executed as (0, 0) (include/oc_level.h) */
+      e->err |= OC_ERR_ACTION;
+      c = 4;
+    }
     e->adx[a] = NAV_DX[c];
     e->ady[a] = NAV_DY[c];
   }
@@ -725,14 +848,21 @@ OC_EXPORT void oc_oracle_batch_multi_step(void **envs, int64_t n0, int64_t n1, i
     int F = 22 + e->S + 2 * C;
     int ego_mv = actions[0 * n_stride + i], ego_cm = actions[1 * n_stride + i];
     int alt_mv = actions[2 * n_stride + i], alt_cm = actions[3 * n_stride + i];
-    comm[i] = communication_on ? ego_cm : -1;                          /* :227-246 */
-    comm[n_stride + i] = (communication_on && !ego_led) ? alt_cm : -1;
+    /* one_hot[idx] = 1 / NAV_ACTIONS[idx] raise IndexError for an index out of range
+     * (:227-248; both move indices are looked up, moved or not): the defined behaviour of
+     * include/oc_level.h OC_ERR_ACTION -- flag, send nothing / stand still */
+    int ego_talks = communication_on, alt_talks = communication_on && !ego_led;
+    int bad = (ego_talks && (ego_cm < 0 || ego_cm >= C)) || (alt_talks && (alt_cm < 0 || alt_cm >= C)) ||
+              ego_mv < 0 || ego_mv > 3 || alt_mv < 0 || alt_mv > 3;
+    comm[i] = (ego_talks && ego_cm >= 0 && ego_cm < C) ? ego_cm : -1;               /* :227-246 */
+    comm[n_stride + i] = (alt_talks && alt_cm >= 0 && alt_cm < C) ? alt_cm : -1;
     int32_t act[OC_MAX_AGENTS] = {4, 4, 4, 4};                         /* :250-262 */
     int ego_slot = ego_agent_idx == 0 ? 0 : 1;
-    if (can_move_mask & 1) act[ego_slot] = ego_mv;
-    if (can_move_mask & 2) act[1 - ego_slot] = alt_mv;
+    if ((can_move_mask & 1) && ego_mv >= 0 && ego_mv <= 3) act[ego_slot] = ego_mv;
+    if ((can_move_mask & 2) && alt_mv >= 0 && alt_mv <= 3) act[1 - ego_slot] = alt_mv;
     int32_t r, d;
     double sh[2];
+    if (bad) e->err |= OC_ERR_ACTION;
     oc_oracle_step(e, act, &r, &d, sh);
     reward[i] = (double)r - sh[0] - sh[1];                             /* :282 */
     done[i] = d;

@@ -75,6 +75,7 @@ def lib():
                                                                          _I32P, _F64P, ctypes.c_int])
         L.oc_oracle_batch_snapshot.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64] + [_I32P] * 7
         L.oc_oracle_batch_reset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, _I32P]
+        L.oc_oracle_pyset_order.argtypes = [_I32P, ctypes.c_int, _I32P]
         _lib = L
     return _lib
 
@@ -347,3 +348,50 @@ class OracleBatch:
             return e.obs(viewer, radius, viewer_blind, ego_blind, C, comm)
         finally:
             e._h = None
+
+
+_TILE_GLYPH = [" ", "-", "/", "*"]          # Floor, Counter, Cutboard, Delivery (utils/core.py:18-26)
+_TYPE_LETTER = ["t", "l", "o", "p"]
+
+
+def render_ascii(blob, snap):
+    """``str(OvercookedEnvironment)`` from an oracle snapshot -- the checker's own rendering,
+    derived from the reference's display code, not from the product's:
+    ``World.update_display`` (gym_cooking/utils/world.py:38-48: every object of
+    ``world.objects`` in iteration order writes ``str(obj)`` at its location, the Tomato-named
+    ones once more), then the agents (overcooked_environment.py:442-446), joined as in
+    ``__str__`` (:62-65).  ``str(Object)`` = its contents sorted by name, ``-``-joined;
+    a Food prints ``<state_index + 1><first letter>``, a Plate ``p`` (utils/core.py:149-377).
+    Grid squares and movable objects share ``world.objects``; a grid square's key is created
+    before any object can sit on it is drawn, and agents are drawn last, so drawing tiles first
+    gives the same picture."""
+    blob = np.asarray(blob)
+    W, H, M = int(blob[2]), int(blob[3]), int(blob[5])
+    cells = blob[int(blob[16]):int(blob[16]) + W * H].reshape(H, W)
+    types = [int(blob[int(blob[19]) + 3 * i]) for i in range(M)]
+    rep = [[_TILE_GLYPH[int(cells[y][x])] for x in range(W)] for y in range(H)]
+    items, order, agents = snap["items"], snap["order"], snap["agents"]
+
+    def obj_str(g):
+        members = sorted((i for i in range(M) if items[i][3] == g),
+                         key=lambda i: ["Tomato", "Lettuce", "Onion", "Plate"][types[i]])
+        return "-".join("p" if types[i] == 3 else "%d%s" % (items[i][2] + 1, _TYPE_LETTER[types[i]])
+                        for i in members)
+
+    groups = [int(g) for g in order if g >= 0]
+    for g in groups:
+        rep[int(items[g][1])][int(items[g][0])] = obj_str(g)
+    for g in groups:                       # `for obj in self.objects["Tomato"]` (world.py:46-47)
+        if [types[i] for i in range(M) if items[i][3] == g] == [0]:
+            rep[int(items[g][1])][int(items[g][0])] = obj_str(g)
+    for a in range(len(agents)):
+        rep[int(agents[a][1])][int(agents[a][0])] = str(a)
+    return "\n".join("".join(c + " " for c in row) for row in rep)
+
+
+def pyset_order(locs):
+    """The oracle's restatement of ``list(set(locs))`` for (x, y) locations, as [(x, y), ...]."""
+    a = np.ascontiguousarray(locs, dtype=np.int32).reshape(-1, 2)
+    out = np.zeros((max(len(a), 1), 2), np.int32)
+    n = lib().oc_oracle_pyset_order(_p32(a), len(a), _p32(out))
+    return [tuple(int(v) for v in out[i]) for i in range(n)]

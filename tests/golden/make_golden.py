@@ -386,6 +386,49 @@ CUSTOM_LEVELS = {
     "custom-two_deliveries": "--*-t-\n/    l\n*    p\n-    p\n------\n\nSimpleTomato\n\n1 1\n3 2\n4 3",
 }
 
+DUP_LEVELS = {
+    # maps that REPEAT a content type (no shipped level does): the reference's engine handles
+    # multisets -- mergeable() has no duplicate check (utils/core.py:240-257), world.objects is a
+    # dict of lists (utils/world.py:236-247), goal counts go above 1
+    # (overcooked_environment.py:408-415) and the `[0]` of a location *set* picks the goal object
+    # the shaping walks to (:287,:374)
+    "custom-two_tomatoes": "-t---t-\n/     l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSimpleTomato\n\n2 1\n4 1\n4 4\n2 4",
+    "custom-two_lettuces_salad": "-l---t-\n/     l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSalad\n\n2 1\n4 1\n4 4\n2 4",
+    "custom-two_tomatoes_small": "-t/t-\n-   p\n*   p\n-----\n\nSimpleTomato\n\n1 1\n3 2\n2 1",
+}
+
+
+def main_dup(summary):
+    H.use_custom_levels(DUP_LEVELS)
+    jobs = [("custom-two_tomatoes", 2, 200, [("purpose", (7000, 80))]),
+            ("custom-two_tomatoes", 3, 150, [("purpose", (4000, 81))]),
+            ("custom-two_lettuces_salad", 2, 250, [("purpose", (9000, 82))]),
+            ("custom-two_tomatoes_small", 2, 120, [("rand5", (1500, 83)), ("purpose", (6000, 84))]),
+            ("custom-two_tomatoes_small", 3, 120, [("purpose", (4000, 85))])]
+    for level, A, T, tapes in jobs:
+        out, sr, nd = run_base(level, A, T, tapes)
+        st = json.loads(str(out["static_json"]))
+        st["level_text"] = DUP_LEVELS[level]
+        out["static_json"] = np.array(json.dumps(st))
+        fn = "cbase_dup_%s_a%d.npz" % (level.replace("custom-", ""), A)
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["t"])), "sum_reward": sr, "episodes": nd,
+                       "steps_with_goal_count_above_1": int((out["goal_count"] > 1).any(axis=1).sum()),
+                       "max_objects": int(out["nobj"].max()), "min_objects": int(out["nobj"].min())}
+        print(fn, summary[fn], "S=%d" % len(st["subtasks"]), flush=True)
+    for name, level, T, steps, seed, kw in [
+            ("dup_two_tomatoes_r2", "custom-two_tomatoes", 200, 6000, 140, {}),
+            ("dup_two_lettuces_salad_c3", "custom-two_lettuces_salad", 250, 8000, 141, {"num_communication": 3, "fow_radius": 1}),
+            ("dup_two_tomatoes_small_r1", "custom-two_tomatoes_small", 120, 5000, 142, {"fow_radius": 1})]:
+        out, nd = run_wrapper(name, level, T, steps, seed, **kw)
+        st = json.loads(str(out["static_json"]))
+        st["level_text"] = DUP_LEVELS[level]
+        out["static_json"] = np.array(json.dumps(st))
+        fn = "cwrap_%s.npz" % name
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["done"])), "episodes": nd}
+        print(fn, summary[fn], flush=True)
+
 
 def main_custom(summary):
     H.use_custom_levels(CUSTOM_LEVELS)
@@ -456,6 +499,13 @@ def main():
             out = run_fow(level, 100, 1500, seed, radius)
             np.savez_compressed(os.path.join(HERE, "fow_%s.npz" % name), **out)
             print("fow_%s.npz" % name, out["maps"].shape, int(out["completed"].sum()))
+        return
+    if "--dup-only" in sys.argv:
+        with open(os.path.join(HERE, "SUMMARY.json")) as f:
+            summary = json.load(f)
+        main_dup(summary)
+        with open(os.path.join(HERE, "SUMMARY.json"), "w") as f:
+            json.dump(summary, f, indent=1, sort_keys=True)
         return
     if "--custom-only" in sys.argv:
         with open(os.path.join(HERE, "SUMMARY.json")) as f:

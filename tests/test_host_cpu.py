@@ -97,7 +97,7 @@ def test_c_abi_exports_every_declared_symbol():
     L = _lib.load()
     for sym in declared:
         assert getattr(L, sym) is not None
-    assert L.oc_abi_version() == 1
+    assert L.oc_abi_version() == _lib.ABI_VERSION == 2
     # argument validation happens before any device work
     assert L.oc_step(None, None, None, None, None, None, 0, None, None, None, 0, None) == -1
     assert b"oc_step" in L.oc_last_error()
@@ -183,6 +183,7 @@ assert g["total"]["env_steps"] == 10010, g
 assert g["total"]["episodes"] == sum(range(1, world + 1)), g
 assert len(g["per_rank"]) == world and g["per_rank"][rank][1] == rank + 1
 assert ocdist.rank_seed(5, rank) != ocdist.rank_seed(5, (rank + 1) %% world)
+assert ocdist.reduce_max([1.0 + rank, 5.0 - rank]) == [float(world), 5.0]
 dist.barrier(); dist.destroy_process_group()
 open(os.path.join(%r, "rank_%%d.ok" %% rank), "w").write("ok")
 """
@@ -317,3 +318,24 @@ def test_no_kernel_spills_to_scratch(tmp_path):
     assert re.search(r"k_multi_step.*?\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", text, re.S)
     pre = [int(v) for v in re.findall(r"\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", text)]
     assert max(pre) >= 10, pre
+
+
+def test_no_jit_compile_under_a_profiler(monkeypatch, tmp_path):
+    """Under rocprofv3 the process has already initialised the GPU and hipcc's exec chain would
+    inherit the profiler's preload: specialize.ensure() must not compile there (cached
+    libraries still load), and the compiler children never see the profiler's variables."""
+    from gym_comm_amd import compiler as C, specialize
+    txt = "-------\n/  t  l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSimpleTomato\n\n2 1\n4 1"
+    (tmp_path / "uncached.txt").write_text(txt)
+    lv = C.compile_level("uncached", 2, level_dir=str(tmp_path))
+    assert not os.path.exists(specialize.spec_lib_path(lv.blob))
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert specialize.profiler_attached()
+    assert specialize.ensure(lv.blob) is None
+    assert not os.path.exists(specialize.spec_lib_path(lv.blob))
+    env = specialize.clean_env()
+    assert "LD_PRELOAD" not in env and not any(k.startswith("ROCP") for k in env)
+    cached = C.compile_level("open-divider_tomato", 2, 500)          # built by __graft_entry__.build()
+    if os.path.exists(specialize.spec_lib_path(cached.blob)):
+        assert specialize.ensure(cached.blob) == specialize.spec_lib_path(cached.blob)

@@ -113,3 +113,19 @@ def test_fow_image_obs_matches_reference(path, oracle_lib):
             assert (img == z["maps"][k][v]).all(), (k, v)
             assert (hold == z["holding"][k]).all(), (k, v)
         assert (env.snapshot()["completed"] == z["completed"][k]).all()
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_oracle_ascii_render_matches_reference_strings(idx, oracle_lib):
+    """oracle.render_ascii (the checker's own str(env)) against the reference's recorded
+    strings of the two scripted solves (tests/golden/ascii_kat.json)."""
+    import json
+    from conftest import GOLDEN
+    from gym_comm_amd import compiler
+    g = json.load(open(os.path.join(GOLDEN, "ascii_kat.json")))[idx]
+    lv = compiler.compile_level(g["level"], g["num_agents"], g["T"], subtask_order=g["subtasks"])
+    env = oracle_lib.OracleEnv(lv.blob)
+    assert oracle_lib.render_ascii(lv.blob, env.snapshot()) == g["reset_str"]
+    for acts, exp in zip(g["script"], g["steps"]):
+        env.step(np.array(acts, np.int32))
+        assert oracle_lib.render_ascii(lv.blob, env.snapshot()) == exp["str"]

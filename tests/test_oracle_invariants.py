@@ -63,3 +63,19 @@ def test_step_invariants(level, A, T, oracle_lib):
             s = ora.snapshot_all()
             assert (s["t"][d == 1] == 0).all() and (s["completed"][d == 1] == 0).all()
         prev = s
+
+
+def test_oracle_set_order_matches_this_interpreter(oracle_lib):
+    """World.get_all_object_locs returns list(set(...)) and the shaping terms take element [0]
+    (world.py:290-291, overcooked_environment.py:287,374): the oracle restates CPython's tuple
+    hash and set table.  Pinned here against the interpreter that recorded the fixtures: random
+    location lists (with repeats) of every size the oracle can meet, full iteration order."""
+    import random
+    rng = random.Random(12)
+    for trial in range(4000):
+        n = rng.randrange(1, 17)
+        locs = [(rng.randrange(16), rng.randrange(16)) for _ in range(n)]
+        if rng.random() < 0.5:                       # repeats: the set drops them
+            locs += [locs[rng.randrange(len(locs))] for _ in range(rng.randrange(3))]
+        locs = locs[:16]
+        assert oracle_lib.pyset_order(locs) == list(set(locs)), locs

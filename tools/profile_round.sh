@@ -8,6 +8,9 @@ set -e
 TAG="$1"; OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+# every library the runs below load is built NOW, outside the profiler: under rocprofv3 the
+# package refuses to JIT-compile a missing specialisation (gym-comm_amd/specialize.py)
+python3 -c 'import __graft_entry__ as g; g.build()' > $OUT/build.log 2>&1
 cfgs=("tomato_n4096 --level open-divider_tomato --agents 2 --envs 4096"
       "salad_n32768 --level full-divider_salad --agents 2 --envs 32768"
       "tl3_n65536 --level partial-divider_tl --agents 3 --envs 65536"
