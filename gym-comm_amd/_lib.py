@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 _I32P = ctypes.POINTER(ctypes.c_int32)
-ABI_VERSION = 2          # include/oc_hip.h: OC_ABI_VERSION
+ABI_VERSION = 3          # include/oc_hip.h: OC_ABI_VERSION
 
 SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destroy",
            "oc_level_spec_source", "oc_is_specialized",
@@ -26,6 +26,13 @@ class WrapCfg(ctypes.Structure):
     _fields_ = [("obs", ObsCfg), ("communication_on", ctypes.c_int32),
                 ("ego_led", ctypes.c_int32), ("ego_agent_idx", ctypes.c_int32),
                 ("can_move_mask", ctypes.c_int32)]
+
+
+class StepOpts(ctypes.Structure):
+    """oc_step_opts (include/oc_hip.h): optional device pointers of oc_multi_step."""
+    _fields_ = [("ep_return", ctypes.c_void_p), ("ep_length", ctypes.c_void_p),
+                ("ego_pairs", ctypes.c_void_p), ("alt_pairs", ctypes.c_void_p),
+                ("alt_rng", ctypes.c_void_p), ("alt_played", ctypes.c_void_p)]
 
 
 class OcError(RuntimeError):
@@ -72,7 +79,7 @@ def _declare(L):
     L.oc_obs.argtypes = [vp, vp, vp, ctypes.POINTER(ObsCfg), vp, vp, ctypes.c_int64, vp]
     L.oc_obs_image.argtypes = [vp, vp, ctypes.c_int32, vp, vp, ctypes.c_int64, vp]
     L.oc_multi_step.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
-                                ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.c_int64, vp]
+                                ctypes.c_int32, vp, vp, vp, ctypes.POINTER(StepOpts), ctypes.c_int64, vp]
     L.oc_random_actions.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
     for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_reset", "oc_step",
               "oc_obs", "oc_obs_image", "oc_multi_step", "oc_random_actions"):

@@ -54,7 +54,8 @@ class BatchedOvercooked:
                 subtask_order=subtask_order, placements=placements, level_dir=level_dir)
         lv = self.level
         if not lv.hip_supported:
-            raise ValueError("level %r repeats a food type; the HIP path does not support it" % lv.name)
+            raise ValueError("level %r: more than three items of one type, or more than 16 distinct "
+                             "merged object names (limits of the packed item words)" % lv.name)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.OcError("BatchedOvercooked needs a ROCm device (got %s); there is no CPU path"
@@ -203,20 +204,50 @@ class BatchedOvercooked:
                                       self._p(self.timestep), self.n, self._stream()), "oc_obs", self._L)
         return self.obs, self.timestep
 
-    def multi_step(self, actions: torch.Tensor, auto_reset: Optional[bool] = None):
+    def multi_step(self, actions: Optional[torch.Tensor] = None, auto_reset: Optional[bool] = None,
+                   ego_pairs: Optional[torch.Tensor] = None, alt_pairs: Optional[torch.Tensor] = None,
+                   alt_rng: Optional[torch.Tensor] = None, alt_played: Optional[torch.Tensor] = None):
         """gym_comm wrapper step in one launch.  actions: int32 [4][n] = ego move (0..3),
-        ego comm, alt move, alt comm.  Returns (obs, timestep, shaped_reward f64[n], done)."""
-        self._check_tensor(actions, (4, self.n), torch.int32, "actions")
+        ego comm, alt move, alt comm.  Per player the (move, comm) may instead come as an
+        int32 [n][2] tensor of pairs (`ego_pairs` / `alt_pairs`: a policy's [n, 2] output as it
+        lies), and the partner may be drawn by the kernel itself, uniformly, from a per-env
+        PCG32 stream (`alt_rng`, int32/uint32 [n]; `alt_played` int32 [2][n] receives the draw)
+        -- include/oc_hip.h, oc_step_opts.  Returns (obs, timestep, shaped_reward f64[n], done)."""
+        n = self.n
+        if actions is not None:
+            self._check_tensor(actions, (4, n), torch.int32, "actions")
+        elif ego_pairs is None or (alt_pairs is None and alt_rng is None):
+            raise ValueError("multi_step needs `actions`, or `ego_pairs` and one of `alt_pairs` / `alt_rng`")
+        if ego_pairs is not None:
+            self._check_tensor(ego_pairs, (n, 2), torch.int32, "ego_pairs")
+        if alt_pairs is not None:
+            self._check_tensor(alt_pairs, (n, 2), torch.int32, "alt_pairs")
+        if alt_rng is not None:
+            self._check_tensor(alt_rng, (n,), torch.int32, "alt_rng")
+        if alt_played is not None:
+            self._check_tensor(alt_played, (2, n), torch.int32, "alt_played")
+        ptr = lambda t: None if t is None else t.data_ptr()
+        self.multi_step_raw(ptr(actions) or 0, ptr(ego_pairs), ptr(alt_pairs), ptr(alt_rng), ptr(alt_played),
+                            int(self.auto_reset if auto_reset is None else auto_reset))
+        return self.obs, self.timestep, self.shaped_reward, self.done
+
+    def multi_step_raw(self, actions_ptr, ego_pairs_ptr, alt_pairs_ptr, alt_rng_ptr, alt_played_ptr, auto_reset):
+        """multi_step on raw device addresses (int, None = absent), nothing checked: the per-call
+        cost is one ctypes call.  For callers that validated their tensors once (vec_env)."""
         a = self._ms_args
-        if a is None:       # every pointer but `actions` is fixed for the life of the env
+        if a is None:       # every pointer but the action sources is fixed for the life of the env
             dp = lambda t: 0 if t is None else t.data_ptr()
+            self._ms_opts = _lib.StepOpts(dp(self.ep_return) or None, dp(self.ep_length) or None,
+                                          None, None, None, None)
             a = self._ms_args = [self._h, dp(self.state), dp(self.comm), 0, ctypes.byref(self._wrap_cfg),
                                  dp(self.obs), dp(self.timestep), dp(self.shaped_reward), dp(self.done),
                                  dp(self.reward), 0, dp(self.metrics), dp(self.placement), dp(self.rng),
-                                 dp(self.ep_return), dp(self.ep_length), self.n, 0]
-        a[3] = actions.data_ptr()
-        a[10] = int(self.auto_reset if auto_reset is None else auto_reset)
-        a[17] = self._raw_stream()
+                                 ctypes.byref(self._ms_opts), self.n, 0]
+        o = self._ms_opts
+        o.ego_pairs, o.alt_pairs, o.alt_rng, o.alt_played = ego_pairs_ptr, alt_pairs_ptr, alt_rng_ptr, alt_played_ptr
+        a[3] = actions_ptr
+        a[10] = auto_reset
+        a[16] = self._raw_stream()
         if torch.cuda.current_device() == self._dev_index:
             rc = self._L.oc_multi_step(*a)
         else:
@@ -224,7 +255,6 @@ class BatchedOvercooked:
                 rc = self._L.oc_multi_step(*a)
         if rc:
             _lib.check(rc, "oc_multi_step", self._L)
-        return self.obs, self.timestep, self.shaped_reward, self.done
 
     def observe_image(self, radius: Optional[int] = None, packed: bool = False):
         """Image-style fog-of-war observation of both viewers
@@ -266,7 +296,14 @@ class BatchedOvercooked:
 
     def snapshot(self):
         """Named fields of every env's state (host numpy), see state.unpack_state."""
-        return unpack_state(self.state.cpu().numpy(), self.A, self.M, self.S)
+        return unpack_state(self.state.cpu().numpy(), self.A, self.M, self.S, **self.unpack_kw())
+
+    def unpack_kw(self):
+        """Extra arguments state.unpack_state needs for this level (dup mode only)."""
+        lv = self.level
+        if not lv.has_dup:
+            return {}
+        return {"goal_index": lv.goal_index, "deliver": [s.kind == compiler.KIND_DELIVER for s in lv.subtasks]}
 
     def fetch(self):
         """ONE device->host copy of everything a step produced: returns {name: numpy view}

@@ -391,11 +391,42 @@ class CompiledLevel:
         return [int(x) | (int(y) << 4) for x, y in cells]
 
     @property
+    def has_dup(self):
+        """Some content type occurs more than once (among the items, or inside a goal object):
+        an Object is then a multiset of types and the HIP library runs its "dup" kernels
+        (include/oc_hip.h).  No shipped level does this."""
+        types = [t for t, _, _ in self.items]
+        if len([t for t in types if t != L.PLATE]) != len({t for t in types if t != L.PLATE}):
+            return True
+        return any(len(set(s.goal_types)) != len(s.goal_types) for s in self.subtasks)
+
+    @property
+    def goal_index(self):
+        """Per subtask, the index of its goal object among the level's distinct goal objects
+        (order of first appearance) -- how dup-mode state words store goal_objects_count."""
+        seen, out = [], []
+        for s in self.subtasks:
+            if s.goal_sig not in seen:
+                seen.append(s.goal_sig)
+            out.append(seen.index(s.goal_sig))
+        return out
+
+    @property
     def hip_supported(self):
-        """The HIP path keys an object by the *set* of its content types, which is
-        exact while every food type occurs at most once in the level."""
-        foods = [t for t, _, _ in self.items if t != L.PLATE]
-        return len(foods) == len(set(foods))
+        """Limits of the HIP path's packed item words: at most three items of one type, at most
+        16 distinct merged names in a level that repeats a type."""
+        types = [t for t, _, _ in self.items]
+        if any(types.count(t) > 3 for t in set(types)):
+            return False
+        if self.has_dup:
+            names = 1
+            for t in (L.TOMATO, L.LETTUCE, L.ONION):
+                names *= types.count(t) + 1
+            names *= 2 if L.PLATE in types else 1
+            singles = sum(1 for t in set(types)) + 1          # the empty multiset and the single contents
+            if names - singles > 16:
+                return False
+        return True
 
 
 def world_order_items(spec: L.LevelSpec, placements=None) -> List[Tuple[int, int, int]]:

@@ -40,6 +40,7 @@ namespace {
 constexpr int MAX_GOALS = 16;   // distinct goal type-sets (all 15 non-empty subsets of 4 types fit)
 constexpr int MAX_DELS = 4;     // Deliver subtasks
 constexpr int MAX_PAIRLK = 12;  // item-pair distance lookups of the shaping pair term
+constexpr int MAX_NAMES = 16;   // dup mode: distinct merged names (4 bits of key rank each, two state words)
 
 // Uniform per-level data.  Generic build: passed by value in the kernel arguments
 // (scalar loads).  Specialised build (-DOC_SPECIALIZED, one .so per level, see
@@ -64,11 +65,19 @@ struct LevelHdr {
   uint32_t pair_static_max;     // name pairs with an absent type: each appends MAX_PATH
   uint32_t ndeliv;
   uint32_t deliv_pos[OC_MAX_DELIV];  // x | y<<4, world order
-  int32_t init_words[OC_MAX_AGENTS + OC_MAX_ITEMS + 2];
+  int32_t init_words[OC_MAX_AGENTS + OC_MAX_ITEMS + 4];
   uint32_t nquot;  // entries in the quotient table
   // random-* levels: items placed on random Counter tiles at every reset
   uint32_t nscatter, ncounters;
   uint32_t scatter_item[4];  // world-order item id of each scattered letter, file order
+  // levels that repeat a content type ("dup" mode; no shipped level does): an Object is then a
+  // MULTISET of types, and the kernels are instantiated with DUP = true
+  uint32_t has_dup;
+  uint32_t goal_sig[MAX_GOALS];  // per distinct goal: its content counts (sig7: T | L<<2 | O<<4 | P<<6)
+  uint32_t del_sig[MAX_DELS];    // the same for the Deliver subtasks, subtask order
+  uint32_t food_items[3];        // per food type: bit i = item i is of that type
+  uint32_t nnames;               // merged names (multisets with >= 2 contents) a merge can create
+  uint32_t name_sig[MAX_NAMES];
 };
 
 // per-run settings that do not select a specialisation
@@ -99,11 +108,57 @@ struct RunCfg {
 #define OC_STAMP_PASS
 #endif
 
+// The kernels read the level through ACCESSORS (L.W(), L.goal_tset(g), ...), one list of fields
+// (OC_HDR_FIELDS) for two header classes:
+//   HdrC  specialised build: every accessor returns a field of the constexpr OC_SPEC_HDR, so loop
+//         bounds, type tests and bit-planes fold at compile time;
+//   HdrK  generic build: the struct travels by value in the kernel arguments and an accessor is a
+//         scalar load from the kernarg segment (uniform, no VGPRs, no LDS, no barrier).
+// (Tried and dropped in round 2: the header spread over the lanes of three VGPRs, one
+// v_readlane per access.  Slower -- 7.68 us per step at 4 096 envs against 6.97 us with kernarg
+// loads: ~290 readlanes with their SGPR-hazard wait states cost more than the scalar-cache hits
+// they replace -- and unsafe: the compiler may copy such a VGPR under a partial EXEC mask, which
+// loses the words parked in inactive lanes.)
+#define OC_HDR_FIELDS(FLD, ARR, ARR64)                                                                     \
+  FLD(int32_t, W) FLD(int32_t, H) FLD(int32_t, ncells) FLD(int32_t, max_path) FLD(int32_t, S)                \
+  FLD(int32_t, A) FLD(int32_t, M) FLD(uint32_t, item_types)                                              \
+  ARR64(nonfloor) ARR64(cell_lo) ARR64(cell_hi)                                                          \
+  FLD(uint32_t, nondeliver_mask) FLD(uint32_t, deliver_mask)                                           \
+  ARR(uint32_t, chop_mask) ARR(uint32_t, food_item)                                                    \
+  FLD(uint32_t, ngoal) ARR(uint32_t, goal_tset) ARR(uint32_t, goal_nd) ARR(uint32_t, goal_dl)             \
+  FLD(uint32_t, ndel) ARR(uint32_t, del_tset) ARR(uint32_t, del_bit)                                     \
+  FLD(uint32_t, npairlk) ARR(uint32_t, pairlk) FLD(uint32_t, pair_static_max)                            \
+  FLD(uint32_t, ndeliv) ARR(uint32_t, deliv_pos) ARR(int32_t, init_words) FLD(uint32_t, nquot)            \
+  FLD(uint32_t, nscatter) FLD(uint32_t, ncounters) ARR(uint32_t, scatter_item)                           \
+  FLD(uint32_t, has_dup) ARR(uint32_t, goal_sig) ARR(uint32_t, del_sig) ARR(uint32_t, food_items)         \
+  FLD(uint32_t, nnames) ARR(uint32_t, name_sig)
+
 #ifdef OC_SPECIALIZED
 #include OC_SPEC_FILE  // constexpr LevelHdr OC_SPEC_HDR = {...};
-#define OC_HDR(p) OC_SPEC_HDR
+struct HdrC {
+#define OC_F(T, name) __device__ __forceinline__ constexpr T name() const { return OC_SPEC_HDR.name; }
+#define OC_A(T, name) __device__ __forceinline__ constexpr T name(int i) const { return OC_SPEC_HDR.name[i]; }
+#define OC_A64(name) __device__ __forceinline__ constexpr uint64_t name(int i) const { return OC_SPEC_HDR.name[i]; }
+  OC_HDR_FIELDS(OC_F, OC_A, OC_A64)
+#undef OC_F
+#undef OC_A
+#undef OC_A64
+};
+using Hdr = HdrC;
+#define OC_HDR_LOAD(args) const HdrC L {}
 #else
-#define OC_HDR(p) (p).L
+struct HdrK {
+  const LevelHdr &k;   // the by-value kernel argument
+#define OC_F(T, name) __device__ __forceinline__ T name() const { return k.name; }
+#define OC_A(T, name) __device__ __forceinline__ T name(int i) const { return k.name[i]; }
+#define OC_A64(name) __device__ __forceinline__ uint64_t name(int i) const { return k.name[i]; }
+  OC_HDR_FIELDS(OC_F, OC_A, OC_A64)
+#undef OC_F
+#undef OC_A
+#undef OC_A64
+};
+using Hdr = HdrK;
+#define OC_HDR_LOAD(args) const HdrK L {(args).L}
 #endif
 
 }  // namespace
@@ -141,14 +196,30 @@ int fail_hip(hipError_t e, const char *what) {
 // an update of several fields is one bit-field insert (v_bfi_b32).
 constexpr int IW_POS = 0x000000FF, IW_CHOP = 0x00000100, IW_GRP = 0x00000E00, IW_HOLD = 0x00007000,
               IW_SEQ = 0x00FF0000, IW_TSET = 0x0F000000;
-constexpr int IW_OBJ = IW_GRP | IW_SEQ | IW_TSET;   // what a merge rewrites
+// "dup" mode (template bool DUP; a level that repeats a content type): bits 24..30 hold the
+// Object's content COUNTS instead of its type set -- T | L<<2 | O<<4 (two bits each, at most
+// three of a food) | P<<6 -- and bits 16..23 hold kseq<<4 | seq: seq = the Object's insertion
+// number as before (4 bits are enough: at most M - 1 <= 7 merges per episode), kseq = the seq of
+// the FIRST Object ever inserted under the same name this episode, i.e. the creation rank of its
+// key in the reference's dict of lists (utils/world.py:21,236-237).  world.objects iterates key
+// by key, so the composite is the world-order rank -- and equals seq<<4 | seq whenever every
+// name is created at most once, which is why non-dup levels never needed it.
+template <bool DUP>
+constexpr int TS = DUP ? 0x7F000000 : IW_TSET;
+template <bool DUP>
+constexpr int OBJ = IW_GRP | IW_SEQ | TS<DUP>;   // what a merge rewrites
+template <bool DUP>
+__host__ __device__ constexpr int sig_of_type(int t) { return DUP ? (1 << (24 + 2 * t)) : (1 << (24 + t)); }
 
-template <int A, int M>
+template <int A, int M, bool DUP>
 struct Env {
   int ap[A], ahp[A];   // agent cell (x | y<<4); held group + 1 (0 = empty hands)
   int iw[M];           // packed item words
   int t, completed, goalcnt, mctr, err;
+  int kn[2];           // DUP: 4 bits per merged name = 1 + seq of the first Object created under it (0 = never)
 };
+template <int A, int M, bool DUP>
+constexpr int state_words() { return A + M + 2 + (DUP ? 2 : 0); }
 
 __device__ __forceinline__ int ipos(int w) { return w & IW_POS; }
 __device__ __forceinline__ int ichop(int w) { return (w >> 8) & 1; }
@@ -157,8 +228,8 @@ __device__ __forceinline__ int iseq(int w) { return (w >> 16) & 255; }
 __device__ __forceinline__ int itset(int w) { return (w >> 24) & 15; }
 __device__ __forceinline__ int bfi(int mask, int a, int b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
 
-template <int A, int M>
-__device__ __forceinline__ void unpack(Env<A, M> &e, const int32_t *w) {
+template <int A, int M, bool DUP>
+__device__ __forceinline__ void unpack(Env<A, M, DUP> &e, const int32_t *w) {
 #pragma unroll
   for (int a = 0; a < A; a++) {
     e.ap[a] = w[a] & 255;
@@ -171,10 +242,11 @@ __device__ __forceinline__ void unpack(Env<A, M> &e, const int32_t *w) {
   e.err = (w[1] >> 24) & 255;
   e.completed = w[A + M];
   e.goalcnt = w[A + M + 1];
+  if constexpr (DUP) e.kn[0] = w[A + M + 2], e.kn[1] = w[A + M + 3];
 }
 
-template <int A, int M>
-__device__ __forceinline__ void pack(const Env<A, M> &e, int32_t *w) {
+template <int A, int M, bool DUP>
+__device__ __forceinline__ void pack(const Env<A, M, DUP> &e, int32_t *w) {
 #pragma unroll
   for (int a = 0; a < A; a++) w[a] = e.ap[a] | (e.ahp[a] << 8);
   w[0] |= e.t << 16;
@@ -183,6 +255,7 @@ __device__ __forceinline__ void pack(const Env<A, M> &e, int32_t *w) {
   for (int i = 0; i < M; i++) w[A + i] = e.iw[i];
   w[A + M] = e.completed;
   w[A + M + 1] = e.goalcnt;
+  if constexpr (DUP) w[A + M + 2] = e.kn[0], w[A + M + 3] = e.kn[1];
 }
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
@@ -198,19 +271,20 @@ __device__ __forceinline__ int manhattan(int p, int q) {   // packed cells x | y
 }
 __device__ __forceinline__ int px(int p) { return p & 15; }
 __device__ __forceinline__ int py(int p) { return p >> 4; }
-__device__ __forceinline__ int dense(const LevelHdr &L, int p) {
-  return (int)(__umul24((unsigned)py(p), (unsigned)L.W) + (unsigned)px(p));  // v_mad_u32_u24
+__device__ __forceinline__ int dense(const Hdr &L, int p) {
+  return (int)(__umul24((unsigned)py(p), (unsigned)L.W()) + (unsigned)px(p));  // v_mad_u32_u24
 }
-__device__ __forceinline__ int bit128(const uint64_t (&w)[2], int c) {
-  const uint64_t v = (c & 64) ? w[1] : w[0];
+// bit c of a 128-bit plane held as two 64-bit words
+__device__ __forceinline__ int bit128(uint64_t w0, uint64_t w1, int c) {
+  const uint64_t v = (c & 64) ? w1 : w0;
   return (int)((v >> (c & 63)) & 1);
 }
-__device__ __forceinline__ int item_type(const LevelHdr &L, int i) { return (L.item_types >> (4 * i)) & 15; }
+__device__ __forceinline__ int item_type(const Hdr &L, int i) { return (L.item_types() >> (4 * i)) & 15; }
 // tile type (OC_FLOOR / COUNTER / CUTBOARD / DELIVERY) of dense cell c
-__device__ __forceinline__ int cell_type(const LevelHdr &L, int c) {
-  if (L.ncells <= 64)  // uniform (compile-time in specialised builds): one 64-bit plane each
-    return (int)((L.cell_lo[0] >> c) & 1) | ((int)((L.cell_hi[0] >> c) & 1) << 1);
-  return bit128(L.cell_lo, c) | (bit128(L.cell_hi, c) << 1);
+__device__ __forceinline__ int cell_type(const Hdr &L, int c) {
+  if (L.ncells() <= 64)  // uniform (compile-time in specialised builds): one 64-bit plane each
+    return (int)((L.cell_lo(0) >> c) & 1) | ((int)((L.cell_hi(0) >> c) & 1) << 1);
+  return bit128(L.cell_lo(0), L.cell_lo(1), c) | (bit128(L.cell_hi(0), L.cell_hi(1), c) << 1);
 }
 
 // Every border cell of the map is a non-Floor tile: agents (always on Floor) can then never
@@ -300,7 +374,75 @@ struct ShapeIn {   // what shaping_lookup() / shaping_sum() still need of the pr
   int ap[B];
   int completed;
   int del_has[MAX_DELS], del_p[MAX_DELS];
+  int chop_p[3];   // DUP: the cell of "the" fresh food of each type (the set's element [0])
 };
+
+// ---------------------------------------------------------------------------
+// dup mode: which location does list(set(locations))[0] return?
+// ---------------------------------------------------------------------------
+// World.get_all_object_locs is list(set(held_locs + unheld_locs)) (utils/world.py:290-291) and
+// calculate_reward_shaping walks to element [0] of it (overcooked_environment.py:287,374-379).
+// With several matching objects that is the location in the LOWEST SLOT of CPython's 8-slot set
+// table: slot = hash((x, y)) & 7, a taken slot sends the newcomer along its probe sequence
+// i <- (5 i + 1 + (perturb >>= 5)) & 7 (Objects/setobject.c; no linear probing in an 8-slot
+// table; the table only grows at the fifth element and at most three objects can match).  The
+// host stores each cell's first eight probe slots, 3 bits each, in a u32 table (`probe`) and
+// checks at level creation that eight are enough for every triple of cells.
+// cand[i]: item i is the representative of a matching Object.  Insertion order: held Objects
+// first, then unheld ones, each in the order of the name's list = ascending seq field.
+template <int M>
+__device__ __forceinline__ int pyset_first(const Hdr &L, const uint32_t *__restrict__ probe,
+                                           const int (&iw)[M], const bool (&cand)[M], int &has) {
+  constexpr int BIG = 1 << 20;
+  int ord[M];
+#pragma unroll
+  for (int i = 0; i < M; i++)
+    ord[i] = cand[i] ? (((iw[i] & IW_HOLD) ? 0 : 256) | ((iw[i] >> 16) & 255)) : BIG;
+  int cell[3], code[3];
+  bool valid[3];
+  int prev = -1;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {   // the k-th candidate in insertion order
+    int cur = BIG, c = 0;
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+      const bool better = ord[i] > prev && ord[i] < cur;
+      cur = better ? ord[i] : cur;
+      c = better ? ipos(iw[i]) : c;
+    }
+    valid[k] = cur != BIG;
+    cell[k] = c;
+    prev = valid[k] ? cur : BIG;
+  }
+  has = valid[0];
+  if (__ballot(valid[1]) == 0) return cell[0];   // one match in every env of the wave: no set order to ask for
+  // a location already in the set is not inserted again
+  valid[1] = valid[1] && cell[1] != cell[0];
+  valid[2] = valid[2] && cell[2] != cell[0] && !(valid[1] && cell[2] == cell[1]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) code[k] = valid[k] ? (int)probe[dense(L, cell[k])] : 0;
+  const int s0 = code[0] & 7;
+  int s1 = 8, s2 = 8;
+  // first free slot along each newcomer's probe sequence (scanned backwards, so the earliest
+  // probe that is free is the one that stays)
+#pragma unroll
+  for (int t = 7; t >= 0; t--) {
+    const int q1 = (code[1] >> (3 * t)) & 7;
+    s1 = (q1 != s0) ? q1 : s1;
+  }
+  s1 = valid[1] ? s1 : 8;
+#pragma unroll
+  for (int t = 7; t >= 0; t--) {
+    const int q2 = (code[2] >> (3 * t)) & 7;
+    s2 = (q2 != s0 && q2 != s1) ? q2 : s2;
+  }
+  s2 = valid[2] ? s2 : 8;
+  int best = cell[0], bs = s0;
+  best = s1 < bs ? cell[1] : best;
+  bs = min(bs, s1);
+  best = s2 < bs ? cell[2] : best;
+  return best;
+}
 template <int B>
 struct ShapeLoads {   // raw path distances, in flight until shaping_lookup()
   int d_chop[3][B];
@@ -313,10 +455,10 @@ struct ShapeLoads {   // raw path distances, in flight until shaping_lookup()
 // interact(), a hundred instructions before the rest, so they are back when shaping_lookup()
 // wants them.  Table offsets are unsigned 24-bit products: full-rate v_mul_u32_u24 /
 // v_mad_u32_u24 and a 32-bit offset on a scalar base (no 64-bit address arithmetic per lookup).
-template <int B, int M>
-__device__ __forceinline__ void shaping_issue_pos(const LevelHdr &L, const uint8_t *__restrict__ dist,
+template <int B, int M, bool DUP>
+__device__ __forceinline__ void shaping_issue_pos(const Hdr &L, const uint8_t *__restrict__ dist,
                                                   const ShapeIn<B> &in, const int (&ipos)[M], ShapeLoads<B> &ld) {
-  const unsigned nc = (unsigned)L.ncells;
+  const unsigned nc = (unsigned)L.ncells();
   unsigned arow[B];
 #pragma unroll
   for (int b = 0; b < B; b++) arow[b] = __umul24((unsigned)dense(L, in.ap[b]), nc);
@@ -327,10 +469,14 @@ __device__ __forceinline__ void shaping_issue_pos(const LevelHdr &L, const uint8
   for (int f = 0; f < 3; f++) {
 #pragma unroll
     for (int b = 0; b < B; b++) ld.d_chop[f][b] = 0;
-    if (L.chop_mask[f] != 0) {  // uniform
+    if (L.chop_mask(f) != 0) {  // uniform
       unsigned fc = 0;
+      if constexpr (DUP) {
+        fc = (unsigned)dense(L, in.chop_p[f]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < M; i++) fc = ((int)L.food_item[f] == i) ? ic[i] : fc;
+        for (int i = 0; i < M; i++) fc = ((int)L.food_item(f) == i) ? ic[i] : fc;
+      }
 #pragma unroll
       for (int b = 0; b < B; b++) ld.d_chop[f][b] = dist[arow[b] + fc];
     }
@@ -338,8 +484,8 @@ __device__ __forceinline__ void shaping_issue_pos(const LevelHdr &L, const uint8
 #pragma unroll
   for (int k = 0; k < MAX_PAIRLK; k++) {
     ld.d_pair[k] = 0;
-    if (k < (int)L.npairlk) {  // uniform
-      const int li = L.pairlk[k] & 15, lj = (L.pairlk[k] >> 4) & 15;
+    if (k < (int)L.npairlk()) {  // uniform
+      const int li = L.pairlk(k) & 15, lj = (L.pairlk(k) >> 4) & 15;
       unsigned ci = 0, cj = 0;
 #pragma unroll
       for (int i = 0; i < M; i++) {
@@ -353,8 +499,8 @@ __device__ __forceinline__ void shaping_issue_pos(const LevelHdr &L, const uint8
   for (int k = 0; k < OC_MAX_DELIV; k++) {
 #pragma unroll
     for (int b = 0; b < B; b++) ld.d_tile[k][b] = 0;
-    if (k < (int)L.ndeliv) {  // uniform
-      const unsigned dc = (unsigned)dense(L, (int)L.deliv_pos[k]);
+    if (k < (int)L.ndeliv()) {  // uniform
+      const unsigned dc = (unsigned)dense(L, (int)L.deliv_pos(k));
 #pragma unroll
       for (int b = 0; b < B; b++) ld.d_tile[k][b] = dist[arow[b] + dc];
     }
@@ -364,14 +510,14 @@ __device__ __forceinline__ void shaping_issue_pos(const LevelHdr &L, const uint8
 // The Deliver-term lookups need the cell of each Deliver subtask's object (known after
 // done/reward).
 template <int B>
-__device__ __forceinline__ void shaping_issue_del(const LevelHdr &L, const uint8_t *__restrict__ dist,
+__device__ __forceinline__ void shaping_issue_del(const Hdr &L, const uint8_t *__restrict__ dist,
                                                   const ShapeIn<B> &in, ShapeLoads<B> &ld) {
-  const unsigned nc = (unsigned)L.ncells;
+  const unsigned nc = (unsigned)L.ncells();
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++) {
 #pragma unroll
     for (int b = 0; b < B; b++) ld.d_del[k][b] = 0;
-    if (k < (int)L.ndel) {  // uniform
+    if (k < (int)L.ndel()) {  // uniform
       const unsigned mc = (unsigned)dense(L, in.del_p[k]);
 #pragma unroll
       for (int b = 0; b < B; b++) ld.d_del[k][b] = dist[__umul24((unsigned)dense(L, in.ap[b]), nc) + mc];
@@ -394,27 +540,27 @@ struct ShapeQ {
 // construction of timestep_of(): exact for every 0 <= k <= 65535, 1 <= MAX_PATH <= 65535
 // (tools/div_check.c).  Replaces a table lookup -- five to seven global loads per env-step
 // that had to be ordered around the stores.
-__device__ __forceinline__ double quotient(int k, const LevelHdr &L, double inv_max_path) {
+__device__ __forceinline__ double quotient(int k, const Hdr &L, double inv_max_path) {
   const double dk = (double)k;
   const double q0 = dk * inv_max_path;
-  const double r = __builtin_fma(-(double)L.max_path, q0, dk);
+  const double r = __builtin_fma(-(double)L.max_path(), q0, dk);
   return __builtin_fma(r, inv_max_path, q0);
 }
 
 template <int B>
-__device__ __forceinline__ void shaping_lookup(const LevelHdr &L, double inv_max_path, const ShapeIn<B> &in,
+__device__ __forceinline__ void shaping_lookup(const Hdr &L, double inv_max_path, const ShapeIn<B> &in,
                                                const ShapeLoads<B> &ld, ShapeQ<B> &q OC_STAMP_PARAM) {
-  const int MAXP = L.max_path;
+  const int MAXP = L.max_path();
   const int completed = in.completed;
   int d_tile[B];  // min over Delivery tiles of path distance + manhattan (:382-388)
 #pragma unroll
   for (int b = 0; b < B; b++) d_tile[b] = 1 << 20;
 #pragma unroll
   for (int k = 0; k < OC_MAX_DELIV; k++)
-    if (k < (int)L.ndeliv) {  // uniform
+    if (k < (int)L.ndeliv()) {  // uniform
 #pragma unroll
       for (int b = 0; b < B; b++)
-        d_tile[b] = min(d_tile[b], ld.d_tile[k][b] + manhattan(in.ap[b], (int)L.deliv_pos[k]));
+        d_tile[b] = min(d_tile[b], ld.d_tile[k][b] + manhattan(in.ap[b], (int)L.deliv_pos(k)));
     }
   // Chop term (:278-304)
   int nchop = 0;
@@ -423,22 +569,22 @@ __device__ __forceinline__ void shaping_lookup(const LevelHdr &L, double inv_max
   for (int b = 0; b < B; b++) mind[b] = 1 << 20;
 #pragma unroll
   for (int f = 0; f < 3; f++)
-    if (L.chop_mask[f] != 0) {  // uniform
-      const int open = __popc((int)L.chop_mask[f] & ~completed);
+    if (L.chop_mask(f) != 0) {  // uniform
+      const int open = __popc((int)L.chop_mask(f) & ~completed);
       nchop += open;
 #pragma unroll
       for (int b = 0; b < B; b++) mind[b] = open ? min(mind[b], ld.d_chop[f][b]) : mind[b];
     }
   // pair term (:319-363): agent independent
-  int npairs = (int)L.pair_static_max;
+  int npairs = (int)L.pair_static_max();
   int minpair = npairs ? MAXP : (1 << 20);
   {
     int cur = MAXP;
 #pragma unroll
     for (int k = 0; k < MAX_PAIRLK; k++)
-      if (k < (int)L.npairlk) {  // uniform
+      if (k < (int)L.npairlk()) {  // uniform
         cur = min(cur, ld.d_pair[k]);
-        if ((L.pairlk[k] >> 8) & 1) {  // uniform: last lookup of this name pair
+        if ((L.pairlk(k) >> 8) & 1) {  // uniform: last lookup of this name pair
           const bool keep = cur != 0;    // a zero distance is not appended (:351-352)
           npairs += keep ? 1 : 0;
           minpair = keep ? min(minpair, cur) : minpair;
@@ -458,7 +604,7 @@ __device__ __forceinline__ void shaping_lookup(const LevelHdr &L, double inv_max
     for (int b = 0; b < B; b++) {
       kq_del[k][b] = 0;
       q.del_direct[k][b] = false;
-      if (k < (int)L.ndel) {
+      if (k < (int)L.ndel()) {
         const int d = ld.d_del[k][b] + manhattan(in.ap[b], in.del_p[k]);
         q.del_direct[k][b] = d == 0;                 // the agent holds it (:381)
         kq_del[k][b] = d == 0 ? d_tile[b] : d;
@@ -470,7 +616,7 @@ __device__ __forceinline__ void shaping_lookup(const LevelHdr &L, double inv_max
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++)
 #pragma unroll
-    for (int b = 0; b < B; b++) q.q_del[k][b] = (k < (int)L.ndel) ? quotient(kq_del[k][b], L, inv_max_path) : 0.0;
+    for (int b = 0; b < B; b++) q.q_del[k][b] = (k < (int)L.ndel()) ? quotient(kq_del[k][b], L, inv_max_path) : 0.0;
   q.nchop = nchop;
   q.npairs = npairs;
   OC_STAMP(4);   // distances consumed, quotients formed
@@ -478,7 +624,7 @@ __device__ __forceinline__ void shaping_lookup(const LevelHdr &L, double inv_max
 
 // last third: the fp64 sums in the reference's order
 template <int B>
-__device__ __forceinline__ void shaping_sum(const LevelHdr &L, const ShapeIn<B> &in, const ShapeQ<B> &q,
+__device__ __forceinline__ void shaping_sum(const Hdr &L, const ShapeIn<B> &in, const ShapeQ<B> &q,
                                             double &s0, double &s1 OC_STAMP_PARAM) {
   double tot[B];
 #pragma unroll
@@ -490,8 +636,8 @@ __device__ __forceinline__ void shaping_sum(const LevelHdr &L, const ShapeIn<B> 
   }
 #pragma unroll
   for (int k = 0; k < MAX_DELS; k++)
-    if (k < (int)L.ndel) {  // uniform; Deliver term in subtask order (:370-395)
-      const bool open = !((in.completed >> L.del_bit[k]) & 1);
+    if (k < (int)L.ndel()) {  // uniform; Deliver term in subtask order (:370-395)
+      const bool open = !((in.completed >> L.del_bit(k)) & 1);
 #pragma unroll
       for (int b = 0; b < B; b++) {
         const double add = !in.del_has[k] ? 2.0 : (q.del_direct[k][b] ? q.q_del[k][b] : q.q_del[k][b] + 1.0);
@@ -510,12 +656,13 @@ __device__ __forceinline__ void shaping_sum(const LevelHdr &L, const ShapeIn<B> 
 // Everything up to done/reward, plus the address formation and the loads of the reward
 // shaping (shaping_issue_*); the caller stores what it has to store and then calls
 // shaping_lookup(L, quot, sin, sld, sq) and, after its stores, shaping_sum(L, sin, sq, ...).
-template <int A, int M>
-__device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
-                                         Env<A, M> &e, const int (&act_in)[A], int &reward, int &done,
+template <int A, int M, bool DUP>
+__device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
+                                         const uint32_t *__restrict__ probe,
+                                         Env<A, M, DUP> &e, const int (&act_in)[A], int &reward, int &done,
                                          int &success, ShapeIn<(A < 2 ? A : 2)> &sin,
                                          ShapeLoads<(A < 2 ? A : 2)> &sld OC_STAMP_PARAM) {
-  const int W = L.W, H = L.H;
+  const int W = L.W(), H = L.H();
   e.t = min(e.t + 1, 0xFFFF);  // :213 (16-bit field: saturates; max_num_timesteps <= 65535 is enforced)
 
   // ---- check_collisions (:578-613) on the ORIGINAL actions -------------------
@@ -588,10 +735,18 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
       tgt_or |= tgt[i] ? u : 0;
     }
     const bool tgt_any = tgt_or != 0;                                   // tset of an item is never empty
-    const bool held_multi = (held_or & IW_TSET & ((held_or & IW_TSET) - (1 << 24))) != 0;  // > 1 content
+    bool held_multi;                                                    // > 1 content
+    if constexpr (DUP) {   // counts: two of one type are two contents
+      int nm = 0;
+#pragma unroll
+      for (int i = 0; i < M; i++) nm += mine[i] ? 1 : 0;
+      held_multi = nm > 1;
+    } else {
+      held_multi = (held_or & IW_TSET & ((held_or & IW_TSET) - (1 << 24))) != 0;
+    }
     const bool held_fresh = (held_or & IW_CHOP) != 0;
     const bool any_fresh = ((held_or | tgt_or) & IW_CHOP) != 0;
-    const bool two_plates = ((held_or & tgt_or) >> (24 + OC_PLATE)) & 1;
+    const bool two_plates = ((held_or & tgt_or) & sig_of_type<DUP>(OC_PLATE)) != 0;
     const bool nf = acting && ct != OC_FLOOR;
     const bool do_move = acting && ct == OC_FLOOR;                       // interact.py:19-20
     const bool at_deliv = ct == OC_DELIVERY;
@@ -607,7 +762,28 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     const int newg = min(holding ? e.ahp[a] - 1 : 7, igrp(tgt_or));  // only used when `take` (then tgt_any)
     // the merged Object: smallest item id as group, re-inserted under a new name = last in
     // world order (world.py:236-237), union of the type sets
-    const int objf = ((held_or | tgt_or) & IW_TSET) | (newg << 9) | ((M + e.mctr) << 16);
+    int objf;
+    if constexpr (DUP) {
+      // the merged name = the two multisets added; its key rank: looked up / entered in the
+      // per-env name table (see Env::kn)
+      const int newsig = (held_or & TS<true>) + (tgt_or & TS<true>);
+      const int seq4 = M + e.mctr;
+      int kf = 0;
+#pragma unroll
+      for (int j = 0; j < MAX_NAMES; j++)
+        if (j < (int)L.nnames()) {   // uniform
+          const bool hit = (newsig >> 24) == (int)L.name_sig(j);
+          const int sh = 4 * (j & 7);
+          const int cur = (e.kn[j >> 3] >> sh) & 15;
+          kf = hit ? cur : kf;
+          const bool enter = hit && cur == 0;   // first Object of this name this episode: the key is created now
+          e.kn[j >> 3] |= (enter && do_merge) ? ((seq4 + 1) << sh) : 0;
+        }
+      const int kseq = kf ? kf - 1 : seq4;
+      objf = newsig | (newg << 9) | (((kseq << 4) | seq4) << 16);
+    } else {
+      objf = ((held_or | tgt_or) & IW_TSET) | (newg << 9) | ((M + e.mctr) << 16);
+    }
     if (A > 2) {
       // World.remove(agent.holding) deletes by (name, location), last match
       // (world.py:239-247): with another agent on the same cell holding a same-named
@@ -626,7 +802,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
         for (int j = 0; j < M; j++) {
           const int w = e.iw[j];
           alias |= (w & IW_HOLD) != 0 && (w & IW_HOLD) != hold_code && ipos(w) == pa &&
-                   ((w ^ held_or) & IW_TSET) == 0 && (w & IW_SEQ) > (held_or & IW_SEQ);
+                   ((w ^ held_or) & TS<DUP>) == 0 && (w & IW_SEQ) > (held_or & IW_SEQ);
         }
         if (shared && do_merge && alias) e.err |= OC_ERR_ALIAS;
       }
@@ -634,9 +810,9 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     // held items: cell <- target (move / put down), holder <- none (put down), object
     // fields (merge), chopped (chop); target-cell items: cell <- agent, holder <- agent
     // (merge / pick up), object fields (merge)
-    const int mask_m = ((do_move || put) ? IW_POS : 0) | (put ? IW_HOLD : 0) | (do_merge ? IW_OBJ : 0) |
+    const int mask_m = ((do_move || put) ? IW_POS : 0) | (put ? IW_HOLD : 0) | (do_merge ? OBJ<DUP> : 0) |
                        (do_chop ? IW_CHOP : 0);
-    const int mask_t = (take ? (IW_POS | IW_HOLD) : 0) | (do_merge ? IW_OBJ : 0);
+    const int mask_t = (take ? (IW_POS | IW_HOLD) : 0) | (do_merge ? OBJ<DUP> : 0);
     const int val_m = tp | IW_CHOP | objf;
     const int val_t = pa | hold_code | objf;
 #pragma unroll
@@ -653,11 +829,25 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   constexpr int B = A < 2 ? A : 2;
 #pragma unroll
   for (int b = 0; b < B; b++) sin.ap[b] = e.ap[b];
+  if constexpr (DUP) {
+    // Chop(X): get_all_object_locs(fresh X)[0] (:287) -- with two fresh X, the set's element [0]
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+      sin.chop_p[f] = 0;
+      if (L.chop_mask(f) != 0) {   // uniform
+        bool cand[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) cand[i] = ((L.food_items(f) >> i) & 1) && !(e.iw[i] & IW_CHOP);
+        int has;
+        sin.chop_p[f] = pyset_first<M>(L, probe, e.iw, cand, has);
+      }
+    }
+  }
   {
     int ipb[M];
 #pragma unroll
     for (int i = 0; i < M; i++) ipb[i] = ipos(e.iw[i]);
-    shaping_issue_pos<B, M>(L, dist, sin, ipb, sld);
+    shaping_issue_pos<B, M, DUP>(L, dist, sin, ipb, sld);
     // keep the lookups HERE: left alone, the scheduler sinks them below done/reward, ~40
     // instructions ahead of their first use
     __builtin_amdgcn_sched_barrier(0);
@@ -667,7 +857,7 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   // present / at_delivery: bit s set iff an Object with type-set s and every food chopped
   // exists (anywhere / on the first Delivery tile).  A multi-item Object is all-chopped
   // by construction (mergeable() required it).
-  const int d0 = (int)L.deliv_pos[0];  // first Delivery tile only (:259,:402)
+  const int d0 = (int)L.deliv_pos(0);  // first Delivery tile only (:259,:402)
   int present = 0, at_delivery = 0;
   bool rep_ok[M];   // item i represents its Object (group == i) and the Object is all-chopped
 #pragma unroll
@@ -676,28 +866,58 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
     const bool rep = (w & IW_GRP) == (i << 9);
     // a lone fresh food is the only Object that is not all-chopped
     const bool lone_fresh =
-        (int)(item_type(L, i) != OC_PLATE) & (int)((w & (IW_TSET | IW_CHOP)) == ((1 << item_type(L, i)) << 24));
+        (int)(item_type(L, i) != OC_PLATE) & (int)((w & (TS<DUP> | IW_CHOP)) == sig_of_type<DUP>(item_type(L, i)));
     rep_ok[i] = (int)rep & (int)!lone_fresh;
-    const int b = rep_ok[i] ? (1 << itset(w)) : 0;
-    present |= b;
-    at_delivery |= ipos(w) == d0 ? b : 0;
-  }
-  int cnt_mask = 0, del_mask = 0;
-#pragma unroll
-  for (int g = 0; g < MAX_GOALS; g++) {
-    if (g < (int)L.ngoal) {  // uniform
-      const bool has = (present >> L.goal_tset[g]) & 1;
-      const bool hasd = (at_delivery >> L.goal_tset[g]) & 1;
-      cnt_mask |= has ? (int)L.goal_nd[g] : 0;
-      del_mask |= hasd ? (int)L.goal_dl[g] : 0;
+    if constexpr (!DUP) {
+      const int b = rep_ok[i] ? (1 << itset(w)) : 0;
+      present |= b;
+      at_delivery |= ipos(w) == d0 ? b : 0;
     }
   }
-  const int newly = cnt_mask & ~e.goalcnt;  // goal count rose above goal_objects_count (:408-415)
+  int cnt_mask = 0, del_mask = 0, newly;
+  if constexpr (DUP) {
+    // a goal object may exist several times: its count = the number of DISTINCT cells that hold
+    // one (get_all_object_locs is a set of locations, world.py:290-291), two bits per goal
+    int rose = 0;
+#pragma unroll
+    for (int g = 0; g < MAX_GOALS; g++)
+      if (g < (int)L.ngoal()) {  // uniform
+        int cnt = 0;
+        bool hasd = false;
+        bool m[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+          m[i] = (int)rep_ok[i] & (int)((e.iw[i] & TS<true>) == ((int)L.goal_sig(g) << 24));
+          bool seen = false;
+#pragma unroll
+          for (int j = 0; j < i; j++) seen |= (int)m[j] & (int)(ipos(e.iw[j]) == ipos(e.iw[i]));
+          cnt += ((int)m[i] & (int)!seen);
+          hasd |= (int)m[i] & (int)(ipos(e.iw[i]) == d0);
+        }
+        cnt = min(cnt, 3);
+        const int old = (e.goalcnt >> (2 * g)) & 3;
+        rose |= cnt > old ? (int)L.goal_nd(g) : 0;
+        cnt_mask |= cnt << (2 * g);
+        del_mask |= hasd ? (int)L.goal_dl(g) : 0;
+      }
+    newly = rose;
+  } else {
+#pragma unroll
+    for (int g = 0; g < MAX_GOALS; g++) {
+      if (g < (int)L.ngoal()) {  // uniform
+        const bool has = (present >> L.goal_tset(g)) & 1;
+        const bool hasd = (at_delivery >> L.goal_tset(g)) & 1;
+        cnt_mask |= has ? (int)L.goal_nd(g) : 0;
+        del_mask |= hasd ? (int)L.goal_dl(g) : 0;
+      }
+    }
+    newly = cnt_mask & ~e.goalcnt;  // goal count rose above goal_objects_count (:408-415)
+  }
   reward = __popc(newly) + 3 * __popc(del_mask);  // Deliver pays +3 every step (:400-406)
   e.completed |= newly | del_mask;
   e.goalcnt = cnt_mask;
   const bool timeout = R.T != 0 && e.t >= R.T;  // checked first (:245-249)
-  const bool all_delivered = del_mask == (int)L.deliver_mask;
+  const bool all_delivered = del_mask == (int)L.deliver_mask();
   done = (timeout || all_delivered) ? 1 : 0;
   success = (!timeout && all_delivered) ? 1 : 0;
 
@@ -707,13 +927,21 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
   for (int k = 0; k < MAX_DELS; k++) {
     sin.del_has[k] = 0;
     sin.del_p[k] = 0;
-    if (k < (int)L.ndel) {  // uniform
+    if (k < (int)L.ndel()) {  // uniform
+      if constexpr (DUP) {   // get_all_object_locs(goal object)[0] (:374-379): the set's element [0]
+        bool cand[M];
 #pragma unroll
-      for (int i = 0; i < M; i++) {
-        // `&`, not `&&`: the short-circuit form became an exec-masked region per item
-        const bool ok = (int)rep_ok[i] & (int)((e.iw[i] & IW_TSET) == ((int)L.del_tset[k] << 24));
-        sin.del_has[k] |= ok;
-        sin.del_p[k] = ok ? ipos(e.iw[i]) : sin.del_p[k];
+        for (int i = 0; i < M; i++)
+          cand[i] = (int)rep_ok[i] & (int)((e.iw[i] & TS<true>) == ((int)L.del_sig(k) << 24));
+        sin.del_p[k] = pyset_first<M>(L, probe, e.iw, cand, sin.del_has[k]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+          // `&`, not `&&`: the short-circuit form became an exec-masked region per item
+          const bool ok = (int)rep_ok[i] & (int)((e.iw[i] & IW_TSET) == ((int)L.del_tset(k) << 24));
+          sin.del_has[k] |= ok;
+          sin.del_p[k] = ok ? ipos(e.iw[i]) : sin.del_p[k];
+        }
       }
     }
   }
@@ -726,8 +954,8 @@ __device__ __forceinline__ void env_step(const LevelHdr &L, const RunCfg &R, con
 // writes F = 22 + S + 2C rows with stride n.
 // OT = element type of the observation rows: 0 int32, 1 int8, 2 float32 (the same integers,
 // converted; what a policy network's first layer consumes as obs[v].T without a cast)
-template <int A, int M, int OT, typename OutRows>
-__device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, int viewer, int radius,
+template <int A, int M, bool DUP, int OT, typename OutRows>
+__device__ __forceinline__ void env_obs(const Hdr &L, const Env<A, M, DUP> &e, int viewer, int radius,
                                         bool viewer_blind, bool ego_blind, int C, int comm0, int comm1,
                                         const OutRows &out, int row0) {
   const int vp = viewer == 0 ? e.ap[0] : e.ap[1];
@@ -776,7 +1004,7 @@ __device__ __forceinline__ void env_obs(const LevelHdr &L, const Env<A, M> &e, i
   for (int ch = 0; ch < 4; ch++) OUT(row++, st[ch]);
 #pragma unroll
   for (int ch = 0; ch < 4; ch++) OUT(row++, hid[ch]);
-  for (int s = 0; s < L.S; s++) OUT(row++, (e.completed >> s) & 1);
+  for (int s = 0; s < L.S(); s++) OUT(row++, (e.completed >> s) & 1);
 #pragma unroll
   for (int k = 0; k < 4; k++) OUT(row++, loc[k]);
   OUT(row++, ego_blind ? 0 : (vhp != 0 ? 1 : 0));  // :154, gated on the EGO's BLIND flag
@@ -869,6 +1097,7 @@ struct MetricsSlot {
 struct Tables {
   const uint8_t *dist;
   const uint8_t *counters;  // Counter tiles (x | y<<4), world order, 64 bytes
+  const uint32_t *probe;    // dup mode: per cell, its first eight set-table probe slots (pyset_first)
 };
 
 template <bool LDS>
@@ -892,9 +1121,11 @@ __device__ __forceinline__ Tables stage_tables(const void *__restrict__ tables, 
     __syncthreads();
     tb.dist = (const uint8_t *)oc_lds + quot_bytes;
     tb.counters = (const uint8_t *)oc_lds + (n16 * 16 - OC_MAX_COUNTERS);
+    tb.probe = (const uint32_t *)((const uint8_t *)oc_lds + (n16 * 16 - OC_MAX_COUNTERS - 4 * OC_MAX_CELLS));
   } else {
     tb.dist = (const uint8_t *)tables;   // quot_bytes is 0 since the quotient table went (v12)
     tb.counters = (const uint8_t *)tables + (n16 * 16 - OC_MAX_COUNTERS);
+    tb.probe = (const uint32_t *)((const uint8_t *)tables + (n16 * 16 - OC_MAX_COUNTERS - 4 * OC_MAX_CELLS));
   }
   return tb;
 }
@@ -911,30 +1142,30 @@ __device__ __forceinline__ uint32_t pcg32(uint32_t &state) {
   return (w >> 22u) ^ w;
 }
 
-template <int A, int M>
-__device__ __forceinline__ void place_items_from(const LevelHdr &L, const Tables &tb, const int32_t *placement,
+template <int A, int M, int WS>
+__device__ __forceinline__ void place_items_from(const Hdr &L, const Tables &tb, const int32_t *placement,
                                                  bool use_rng, uint32_t &st, int64_t n, int64_t i,
-                                                 int32_t (&w)[A + M + 2]) {
-  if (L.nscatter == 0) return;  // uniform (compile-time in specialised builds)
+                                                 int32_t (&w)[WS]) {
+  if (L.nscatter() == 0) return;  // uniform (compile-time in specialised builds)
   int pos[M];
 #pragma unroll
   for (int k = 0; k < M; k++) pos[k] = w[A + k] & 255;
   if (use_rng) {
     unsigned long long taken = 0;
-    for (int k = 0; k < (int)L.nscatter; k++) {
+    for (int k = 0; k < (int)L.nscatter(); k++) {
       int idx = 0;
       bool ok = false;
       for (int attempt = 0; attempt < 64 && !ok; attempt++) {
-        idx = (int)__umulhi(pcg32(st), L.ncounters);
+        idx = (int)__umulhi(pcg32(st), L.ncounters());
         ok = !((taken >> idx) & 1);
       }
-      for (int c = 0; c < (int)L.ncounters && !ok; c++) {  // practically unreachable
+      for (int c = 0; c < (int)L.ncounters() && !ok; c++) {  // practically unreachable
         idx = c;
         ok = !((taken >> idx) & 1);
       }
       taken |= 1ull << idx;
       const int cell = tb.counters[idx];
-      const int item = (int)L.scatter_item[k & 3];
+      const int item = (int)L.scatter_item(k & 3);
 #pragma unroll
       for (int m = 0; m < M; m++) pos[m] = (item == m) ? cell : pos[m];
     }
@@ -947,13 +1178,13 @@ __device__ __forceinline__ void place_items_from(const LevelHdr &L, const Tables
 }
 
 // read-modify-write form: the env's PCG32 state lives in rng[i]
-template <int A, int M>
-__device__ __forceinline__ void place_items(const LevelHdr &L, const Tables &tb, const int32_t *placement,
-                                            uint32_t *rng, int64_t n, int64_t i, int32_t (&w)[A + M + 2]) {
-  if (L.nscatter == 0) return;
+template <int A, int M, int WS>
+__device__ __forceinline__ void place_items(const Hdr &L, const Tables &tb, const int32_t *placement,
+                                            uint32_t *rng, int64_t n, int64_t i, int32_t (&w)[WS]) {
+  if (L.nscatter() == 0) return;
   const bool use_rng = rng != nullptr;
   uint32_t st = use_rng ? rng[i] : 0u;
-  place_items_from<A, M>(L, tb, placement, use_rng, st, n, i, w);
+  place_items_from<A, M, WS>(L, tb, placement, use_rng, st, n, i, w);
   if (use_rng) rng[i] = st;
 }
 
@@ -975,7 +1206,7 @@ struct StepArgs {
 };
 
 // (leading scalars: preloaded kernel arguments, see k_multi_step)
-template <int A, int M, bool LDS, bool WT>
+template <int A, int M, bool LDS, bool WT, bool DUP>
 __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32_t *const actions_,
                                               int64_t *const metrics_, const int64_t n_, const int32_t launch_,
                                               const int32_t T_, const void *const tables_,
@@ -984,7 +1215,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
   // auto-reset flag too: this kernel runs at the SGPR limit with 3-4 agents, and the compiler
   // otherwise loads each of them right before its first use and waits on the spot)
   using Out = RowsT<WT ? AUX_WT : 0>;
-  const LevelHdr &L = OC_HDR(p);
+  OC_HDR_LOAD(p);
   const int block_ = launch_ & 0xFFFF;
   const bool auto_reset_ = (launch_ >> 16) & 1;
   const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
@@ -995,7 +1226,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
-    constexpr int WS = A + M + 2;
+    constexpr int WS = state_words<A, M, DUP>();
     const Out st(state_, n_, WS, i);
     const Rows ac(actions_, n_, A, i);
     int32_t w[WS];
@@ -1005,8 +1236,8 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
 #pragma unroll
     for (int a = 0; a < A; a++) act[a] = ac.ld(a);
     if constexpr (!LDS) tb = stage_tables<false>(tables_, p.n16, p.quot_bytes);
-    Env<A, M> e;
-    unpack<A, M>(e, w);
+    Env<A, M, DUP> e;
+    unpack<A, M, DUP>(e, w);
     const int err_before = e.err;
     constexpr int B = A < 2 ? A : 2;
     ShapeIn<B> sin;
@@ -1016,7 +1247,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
 #endif
     RunCfg R = p.R;
     R.T = T_;   // the preloaded copy
-    env_step<A, M>(L, R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
+    env_step<A, M, DUP>(L, R, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     ShapeQ<B> sq;
@@ -1025,10 +1256,10 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
     Out(p.done, p.n, 1, i).st(0, done);
     if (done && auto_reset_) {
 #pragma unroll
-      for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
-      place_items<A, M>(L, tb, p.placement, p.rng, p.n, i, w);
+      for (int r = 0; r < WS; r++) w[r] = L.init_words(r);
+      place_items<A, M, WS>(L, tb, p.placement, p.rng, p.n, i, w);
     } else {
-      pack<A, M>(e, w);
+      pack<A, M, DUP>(e, w);
     }
 #pragma unroll
     for (int r = 0; r < WS; r++) st.st(r, w[r]);
@@ -1052,27 +1283,27 @@ struct ObsArgs {
   oc_obs_cfg cfg;
 };
 
-template <int A, int M, int OT, bool WT>
+template <int A, int M, int OT, bool WT, bool DUP>
 __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
   using Out = RowsT<WT ? AUX_WT : 0>;
-  const LevelHdr &L = OC_HDR(p);
+  OC_HDR_LOAD(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
-  constexpr int WS = A + M + 2;
+  constexpr int WS = state_words<A, M, DUP>();
   const Rows st(p.state, p.n, WS, i);
   int32_t w[WS];
 #pragma unroll
   for (int r = 0; r < WS; r++) w[r] = st.ld(r);
-  Env<A, M> e;
-  unpack<A, M>(e, w);
+  Env<A, M, DUP> e;
+  unpack<A, M, DUP>(e, w);
   const int C = p.cfg.num_comm;
-  const int F = 22 + L.S + 2 * C;
+  const int F = 22 + L.S() + 2 * C;
   const int c0 = p.comm[i], c1 = p.comm[p.n + i];
   const bool ego_blind = p.cfg.blind_mask & 1;
   const Out ob(p.obs, p.n, 2 * F, i, OT == 1 ? 1 : 4);
 #pragma unroll
   for (int v = 0; v < 2; v++)
-    env_obs<A, M, OT>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
+    env_obs<A, M, DUP, OT>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
   Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));  // overcooked_env.py:146
 }
 
@@ -1094,19 +1325,19 @@ struct ImageArgs {
 // every plane.  Rows are int8; a lane packs FOUR consecutive rows of its env into one dword
 // (little-endian, zero padded past the last row), so a wave stores 256 contiguous bytes per
 // instruction: 172 dword stores per viewer-pair and wave at 7x7 instead of 686 byte stores.
-template <int A, int M>
+template <int A, int M, bool DUP>
 __global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
-  const LevelHdr &L = OC_HDR(p);
+  OC_HDR_LOAD(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
-  constexpr int WS = A + M + 2;
+  constexpr int WS = state_words<A, M, DUP>();
   const Rows st(p.state, p.n, WS, i);
   int32_t w[WS];
 #pragma unroll
   for (int r = 0; r < WS; r++) w[r] = st.ld(r);
-  Env<A, M> e;
-  unpack<A, M>(e, w);
-  const int W = L.W, H = L.H;
+  Env<A, M, DUP> e;
+  unpack<A, M, DUP>(e, w);
+  const int W = L.W(), H = L.H();
   const int rows = 7 * W * H, R4 = (rows + 3) >> 2;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(2 * R4 * p.n * 4), 0x00020000);
@@ -1118,11 +1349,15 @@ __global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
       if (4 * r4 + b < rows) {   // uniform
         const int cell = x | (y << 4);
         int val = k == 0 ? cell_type(L, y * W + x) : 0;
-        if (k >= 3) {   // uniform; world order is irrelevant: one writer per (plane, cell) value
+        if (k >= 3) {   // uniform; the last writer in world order wins (:171-178) -- it only matters when
+          int best = -1;  // two items of one type share a cell (dup levels)
 #pragma unroll
           for (int m = 0; m < M; m++)
-            if (item_type(L, m) + 3 == k)   // uniform
-              val = ipos(e.iw[m]) == cell ? (k == 3 + OC_PLATE ? 1 : ichop(e.iw[m]) + 1) : val;
+            if (item_type(L, m) + 3 == k) {   // uniform
+              const bool hit = ipos(e.iw[m]) == cell && (e.iw[m] & IW_SEQ) > best;
+              val = hit ? (k == 3 + OC_PLATE ? 1 : ichop(e.iw[m]) + 1) : val;
+              best = hit ? (e.iw[m] & IW_SEQ) : best;
+            }
         }
 #pragma unroll
         for (int a = 0; a < A; a++)
@@ -1158,18 +1393,18 @@ struct ResetArgs {
 };
 
 // OvercookedEnvironment.reset() (overcooked_environment.py:180-206), masked
-template <int A, int M>
+template <int A, int M, bool DUP>
 __global__ void __launch_bounds__(256) k_reset(const ResetArgs p) {
-  const LevelHdr &L = OC_HDR(p);
+  OC_HDR_LOAD(p);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
   if (p.mask != nullptr && p.mask[i] == 0) return;
-  constexpr int WS = A + M + 2;
+  constexpr int WS = state_words<A, M, DUP>();
   const Tables tb = stage_tables<false>(p.tables, p.n16, p.quot_bytes);
   int32_t w[WS];
 #pragma unroll
-  for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
-  place_items<A, M>(L, tb, p.placement, p.rng, p.n, i, w);
+  for (int r = 0; r < WS; r++) w[r] = L.init_words(r);
+  place_items<A, M, WS>(L, tb, p.placement, p.rng, p.n, i, w);
 #pragma unroll
   for (int r = 0; r < WS; r++) p.state[(int64_t)r * p.n + i] = w[r];
 }
@@ -1201,15 +1436,16 @@ struct MultiArgs {
   int64_t *metrics;
   const int32_t *placement;
   uint32_t *rng;
-  double *ep_return;     // per-env episode statistics (include/oc_hip.h), NULL = off
-  int32_t *ep_length;
+  oc_step_opts opt;      // optional inputs / outputs (include/oc_hip.h), all NULL = off
   int64_t n;
   int32_t auto_reset;
   oc_wrap_cfg cfg;
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
-template <int M, bool LDS, int OT, bool WT>
+// XO = false: the plain step (actions from the four rows, no episode statistics): `p.opt` is not
+// even looked at, so the optional features cost the headline path nothing.
+template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO>
 __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
                                                     int32_t *const comm_, int64_t *const metrics_,
                                                     const int64_t n_, const int32_t block_,
@@ -1218,11 +1454,15 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   // otherwise come from the hidden arguments): as plain leading arguments they are preloaded
   // into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, build.py), so the state
   // and action loads are issued without first waiting for a scalar kernarg load.
+  // (block_ = workgroup size | which optional action sources are in use << 16: the branches on
+  // them are taken on a preloaded SGPR, not on a pointer that a scalar load has yet to deliver)
   constexpr int A = 2;
   using Out = RowsT<WT ? AUX_WT : 0>;
-  const LevelHdr &L = OC_HDR(p);
-  const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
+  OC_HDR_LOAD(p);
+  const int i = (int)blockIdx.x * (block_ & 0xFFFF) + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
   const bool valid = i < (int)n_;
+  const bool ego_from_pairs = XO && ((block_ >> 16) & 1), alt_from_pairs = XO && ((block_ >> 17) & 1),
+             alt_from_rng = XO && ((block_ >> 18) & 1);
 #ifdef OC_STAMPS
   unsigned long long oc_tt[16];
   for (int k = 0; k < 16; k++) oc_tt[k] = 0;
@@ -1237,32 +1477,62 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
   if (valid) {
-    constexpr int WS = A + M + 2;
+    constexpr int WS = state_words<A, M, DUP>();
     const Out st(state_, n_, WS, i), cm(comm_, n_, 2, i);
-    const Rows ac(actions_, n_, 4, i);
     int32_t w[WS];
 #pragma unroll
     for (int r = 0; r < WS; r++) w[r] = st.ld(r);
-    const int ego_mv = ac.ld(0), ego_cm = ac.ld(1), alt_mv = ac.ld(2), alt_cm = ac.ld(3);
+    // The two players' (move, comm): rows 0..3 of `actions` [4][n] -- or, per player, an
+    // [n][2] array of pairs (the batched form of multi_step's ego_action / alt_action tuples: a
+    // policy's [n, 2] output is consumed as it lies); the partner may also be drawn here,
+    // uniformly from the env's own PCG32 stream (oc_step_opts).  All three tests are uniform.
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    int ego_mv, ego_cm, alt_mv, alt_cm;
+    if (ego_from_pairs) {
+      const Rows pr(p.opt.ego_pairs, n_, 1, i, 8);
+      const v2i q = (v2i)__builtin_amdgcn_raw_buffer_load_b64(pr.rsrc, pr.voff, 0, 0);
+      ego_mv = q.x, ego_cm = q.y;
+    } else {
+      const Rows ac(actions_, n_, 4, i);
+      ego_mv = ac.ld(0), ego_cm = ac.ld(1);
+    }
+    if (alt_from_rng) {
+      uint32_t rs = (uint32_t)Rows(p.opt.alt_rng, n_, 1, i).ld(0);
+      alt_mv = (int)__umulhi(pcg32(rs), 4u);
+      alt_cm = (int)__umulhi(pcg32(rs), (uint32_t)p.cfg.obs.num_comm);
+      Rows(p.opt.alt_rng, n_, 1, i).st(0, (int)rs);
+      if (p.opt.alt_played != nullptr) {
+        const Rows ap(p.opt.alt_played, n_, 2, i);
+        ap.st(0, alt_mv);
+        ap.st(1, alt_cm);
+      }
+    } else if (alt_from_pairs) {
+      const Rows pr(p.opt.alt_pairs, n_, 1, i, 8);
+      const v2i q = (v2i)__builtin_amdgcn_raw_buffer_load_b64(pr.rsrc, pr.voff, 0, 0);
+      alt_mv = q.x, alt_cm = q.y;
+    } else {
+      const Rows ac(actions_, n_, 4, i);
+      alt_mv = ac.ld(2), alt_cm = ac.ld(3);
+    }
     if constexpr (!LDS) tb = stage_tables<false>(p.tables, p.n16, p.quot_bytes);
     // the output pointers are needed hundreds of instructions from here, where the compiler
     // would place their scalar loads -- and a wait on them -- in the middle of the step; fetch
     // them now, under the wait for the state that has to be served anyway
     asm volatile("" ::"s"(tb.dist), "s"(p.obs), "s"(p.timestep), "s"(p.reward), "s"(p.done),
                  "s"(p.sparse), "s"(p.auto_reset), "s"(p.R.inv_T), "s"(p.R.inv_max_path));
+    if constexpr (XO) asm volatile("" ::"s"(p.opt.ep_return), "s"(p.opt.ep_length));
     // episode statistics: the running return / length and the previous step's done flag are
     // loaded now, with the state, and consumed after the last store of the step
     double ep_ret = 0.0;
     int ep_len = 0, prev_done = 0;
-    if (p.ep_return != nullptr) {   // uniform
-      typedef int v2i __attribute__((ext_vector_type(2)));
-      const Rows er(p.ep_return, n_, 1, i, 8);
+    if (XO && p.opt.ep_return != nullptr) {   // uniform
+      const Rows er(p.opt.ep_return, n_, 1, i, 8);
       ep_ret = __builtin_bit_cast(double, (v2i)__builtin_amdgcn_raw_buffer_load_b64(er.rsrc, er.voff, 0, 0));
-      ep_len = Rows(p.ep_length, n_, 1, i).ld(0);
+      ep_len = Rows(p.opt.ep_length, n_, 1, i).ld(0);
       prev_done = Rows(p.done, n_, 1, i).ld(0);
     }
-    Env<A, M> e;
-    unpack<A, M>(e, w);
+    Env<A, M, DUP> e;
+    unpack<A, M, DUP>(e, w);
     OC_STAMP(1);   // state + actions arrived
     // comm one-hots (:227-246); an index the reference's one_hot[idx] = 1 would raise on is
     // flagged (OC_ERR_ACTION) and sends nothing
@@ -1285,7 +1555,7 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     e.err |= (bad_mv | bad_cm) ? OC_ERR_ACTION : 0;
     ShapeIn<2> sin;
     ShapeLoads<2> sld;
-    env_step<A, M>(L, p.R, tb.dist, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
+    env_step<A, M, DUP>(L, p.R, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     Out(p.done, p.n, 1, i).st(0, done);
@@ -1294,23 +1564,23 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
 #endif
     if (done && p.auto_reset) {
 #pragma unroll
-      for (int r = 0; r < WS; r++) w[r] = L.init_words[r];
-      place_items<A, M>(L, tb, p.placement, p.rng, p.n, i, w);
-      unpack<A, M>(e, w);
+      for (int r = 0; r < WS; r++) w[r] = L.init_words(r);
+      place_items<A, M, WS>(L, tb, p.placement, p.rng, p.n, i, w);
+      unpack<A, M, DUP>(e, w);
     } else {
-      pack<A, M>(e, w);
+      pack<A, M, DUP>(e, w);
     }
 #pragma unroll
     for (int r = 0; r < WS; r++) st.st(r, w[r]);
     ShapeQ<2> sq;
     shaping_lookup<2>(L, p.R.inv_max_path, sin, sld, sq OC_STAMP_PASS);
     const int C = p.cfg.obs.num_comm;
-    const int F = 22 + L.S + 2 * C;
+    const int F = 22 + L.S() + 2 * C;
     const bool ego_blind = p.cfg.obs.blind_mask & 1;
     const Out ob(p.obs, p.n, 2 * F, i, OT == 1 ? 1 : 4);
 #pragma unroll
     for (int v = 0; v < 2; v++)
-      env_obs<A, M, OT>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
+      env_obs<A, M, DUP, OT>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
                         v * F);
     Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
     OC_STAMP(5);   // observation stores issued
@@ -1319,9 +1589,9 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     shaping_sum<2>(L, sin, sq, s0, s1 OC_STAMP_PASS);
     const double shaped = ((double)reward - s0) - s1;  // :282
     Out(p.reward, p.n, 1, i, 8).st_f64(0, shaped);
-    if (p.ep_return != nullptr) {   // uniform
-      Out(p.ep_return, p.n, 1, i, 8).st_f64(0, prev_done ? shaped : ep_ret + shaped);
-      Out(p.ep_length, p.n, 1, i).st(0, prev_done ? 1 : ep_len + 1);
+    if (XO && p.opt.ep_return != nullptr) {   // uniform
+      Out(p.opt.ep_return, p.n, 1, i, 8).st_f64(0, prev_done ? shaped : ep_ret + shaped);
+      Out(p.opt.ep_length, p.n, 1, i).st(0, prev_done ? 1 : ep_len + 1);
     }
   }
   OC_STAMP(7);   // every store issued
@@ -1375,8 +1645,9 @@ int launch_st(K kernel, const StepArgs &a, int64_t n, void *stream, size_t lds_b
 }
 template <typename K>
 int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
+  const int32_t src = (a.opt.ego_pairs ? 1 : 0) | (a.opt.alt_pairs ? 2 : 0) | (a.opt.alt_rng ? 4 : 0);
   return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.comm, a.metrics, a.n,
-                  (int32_t)block_size_for(n), a);
+                  (int32_t)(block_size_for(n) | (src << 16)), a);
 }
 
 bool write_through(int64_t n) {
@@ -1393,21 +1664,26 @@ bool tables_in_lds(int64_t) {
   return forced == 1;
 }
 
+// X(A, M, DUP): one instantiation per (agents, items, dup mode).  `A_`, `M_`, `D_` are locals of
+// the caller.
 #ifdef OC_SPECIALIZED
-#define OC_FOR_AM(X)                                                                     \
-  if (A_ == OC_SPEC_HDR.A && M_ == OC_SPEC_HDR.M) { X(OC_SPEC_HDR.A, OC_SPEC_HDR.M); }  \
+constexpr bool OC_SPEC_DUP = OC_SPEC_HDR.has_dup != 0;
+#define OC_FOR_AM(X)                                                                                  \
+  if (A_ == OC_SPEC_HDR.A && M_ == OC_SPEC_HDR.M && D_ == OC_SPEC_DUP) { X(OC_SPEC_HDR.A, OC_SPEC_HDR.M, OC_SPEC_DUP); } \
   return fail(OC_E_BADARG, "specialised library built for another (num_agents, num_items)");
 #else
-#define OC_FOR_AM(X)                          \
-  if (A_ == 2 && M_ == 3) { X(2, 3); }        \
-  if (A_ == 2 && M_ == 4) { X(2, 4); }        \
-  if (A_ == 2 && M_ == 5) { X(2, 5); }        \
-  if (A_ == 3 && M_ == 3) { X(3, 3); }        \
-  if (A_ == 3 && M_ == 4) { X(3, 4); }        \
-  if (A_ == 3 && M_ == 5) { X(3, 5); }        \
-  if (A_ == 4 && M_ == 3) { X(4, 3); }        \
-  if (A_ == 4 && M_ == 4) { X(4, 4); }        \
-  if (A_ == 4 && M_ == 5) { X(4, 5); }        \
+#define OC_FOR_AM_D(X, DD)                        \
+  if (A_ == 2 && M_ == 3) { X(2, 3, DD); }        \
+  if (A_ == 2 && M_ == 4) { X(2, 4, DD); }        \
+  if (A_ == 2 && M_ == 5) { X(2, 5, DD); }        \
+  if (A_ == 3 && M_ == 3) { X(3, 3, DD); }        \
+  if (A_ == 3 && M_ == 4) { X(3, 4, DD); }        \
+  if (A_ == 3 && M_ == 5) { X(3, 5, DD); }        \
+  if (A_ == 4 && M_ == 3) { X(4, 3, DD); }        \
+  if (A_ == 4 && M_ == 4) { X(4, 4, DD); }        \
+  if (A_ == 4 && M_ == 5) { X(4, 5, DD); }
+#define OC_FOR_AM(X)                              \
+  if (D_) { OC_FOR_AM_D(X, true) } else { OC_FOR_AM_D(X, false) } \
   return fail(OC_E_BADARG, "unsupported (num_agents, num_items): need A in 2..4, M in 3..5");
 #endif
 
@@ -1416,6 +1692,45 @@ int tset_of_sig(int sig) {
   for (int t = 0; t < OC_NTYPES; t++)
     if ((sig >> (4 * t)) & 15) ts |= 1 << t;
   return ts;
+}
+// nibble counts (include/oc_level.h goal_sig) -> the 7-bit form the dup-mode item words carry
+// (two bits per food type, bit 6 the Plate); -1 when a count does not fit
+int sig7_of_sig(int sig) {
+  int out = 0;
+  for (int t = 0; t < OC_NTYPES; t++) {
+    const int c = (sig >> (4 * t)) & 15;
+    if (c > (t == OC_PLATE ? 1 : 3)) return -1;
+    out |= c << (2 * t);
+  }
+  return out;
+}
+
+// hash((x, y)) of CPython >= 3.8 for small non-negative ints (Objects/tupleobject.c: the
+// xxHash-style tuplehash; hash(int) is the int) -- what orders list(set(locations)), see pyset_first
+uint64_t py_hash_xy(int x, int y) {
+  const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
+  uint64_t acc = P5;
+  const uint64_t lane[2] = {(uint64_t)x, (uint64_t)y};
+  for (int k = 0; k < 2; k++) {
+    acc += lane[k] * P2;
+    acc = (acc << 31) | (acc >> 33);
+    acc *= P1;
+  }
+  acc += 2ULL ^ (P5 ^ 3527539ULL);
+  return acc == (uint64_t)-1 ? 1546275796ULL : acc;
+}
+// the first eight probe slots of a location in an 8-slot set table, 3 bits each
+// (Objects/setobject.c set_add_entry: i = hash & 7, then i = (5 i + 1 + (perturb >>= 5)) & 7)
+uint32_t probe_code(int x, int y) {
+  const uint64_t h = py_hash_xy(x, y);
+  uint64_t perturb = h;
+  uint32_t i = (uint32_t)(h & 7), code = 0;
+  for (int t = 0; t < 8; t++) {
+    code |= i << (3 * t);
+    perturb >>= 5;
+    i = (uint32_t)((i * 5 + 1 + perturb) & 7);
+  }
+  return code;
 }
 
 // Level blob (include/oc_level.h) -> LevelHdr + RunCfg.  Host only, no device work.
@@ -1448,23 +1763,48 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
     if (cells[c] & 2) h.cell_hi[c >> 6] |= bit;
   }
   for (int f = 0; f < 3; f++) h.food_item[f] = 255;
+  int type_count[OC_NTYPES] = {0, 0, 0, 0};
   for (int i = 0; i < M; i++) {
     const int t = it[3 * i];
     if (t < 0 || t >= OC_NTYPES) return "bad item type";
+    if (i > 0 && t != it[3 * (i - 1)] && type_count[t] > 0) return "items must be grouped by type (world order)";
+    type_count[t]++;
     if (t != OC_PLATE) {
-      if (h.food_item[t] != 255) return "a food type occurs twice (unsupported by the HIP path)";
-      h.food_item[t] = (uint32_t)i;
+      if (h.food_item[t] != 255) h.has_dup = 1;   // a food type occurs twice: dup mode
+      else h.food_item[t] = (uint32_t)i;
+      h.food_items[t] |= 1u << i;
     }
     h.item_types |= (uint32_t)t << (4 * i);
   }
+  for (int t = 0; t < OC_NTYPES; t++)
+    if (type_count[t] > 3) return "more than three items of one type";
+  for (int s = 0; s < S; s++)
+    for (int t = 0; t < OC_NTYPES; t++)
+      if (((st[4 * s + 1] >> (4 * t)) & 15) > 1) h.has_dup = 1;   // a goal object repeats a content type
+  if (h.has_dup) {
+    // the names a merge can create: every multiset of >= 2 contents drawn from the level's
+    // items with at most one Plate (mergeable(), utils/core.py:240-257, checks nothing else)
+    const int cp = type_count[OC_PLATE] > 0 ? 1 : 0;
+    for (int a = 0; a <= type_count[0]; a++)
+      for (int b2 = 0; b2 <= type_count[1]; b2++)
+        for (int c = 0; c <= type_count[2]; c++)
+          for (int d = 0; d <= cp; d++)
+            if (a + b2 + c + d >= 2) {
+              if (h.nnames >= (uint32_t)MAX_NAMES) return "too many distinct merged object names";
+              h.name_sig[h.nnames++] = (uint32_t)(a | (b2 << 2) | (c << 4) | (d << 6));
+            }
+  }
   for (int s = 0; s < S; s++) {
     const int kind = st[4 * s], sig = st[4 * s + 1], food = st[4 * s + 2];
-    for (int t = 0; t < OC_NTYPES; t++)
-      if (((sig >> (4 * t)) & 15) > 1) return "goal object repeats a content type";
-    const int ts = tset_of_sig(sig);
+    const int s7 = sig7_of_sig(sig);
+    if (s7 < 0) return "goal object holds more than three of a food or two Plates";
+    // goals are told apart by their multiset in dup mode, by their type set otherwise (the same
+    // thing when nothing repeats)
+    const int ts = h.has_dup ? s7 : tset_of_sig(sig);
     if (kind == OC_DELIVER) {
       h.deliver_mask |= 1u << s;
       if (h.ndel >= (uint32_t)MAX_DELS) return "too many Deliver subtasks";
+      h.del_sig[h.ndel] = (uint32_t)s7;
       h.del_tset[h.ndel] = (uint32_t)ts;
       h.del_bit[h.ndel] = (uint32_t)s;
       h.ndel++;
@@ -1480,6 +1820,7 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
       if (h.goal_tset[g] == (uint32_t)ts) break;
     if (g == h.ngoal) {
       if (h.ngoal >= (uint32_t)MAX_GOALS) return "too many distinct goal objects";
+      h.goal_sig[h.ngoal] = (uint32_t)s7;
       h.goal_tset[h.ngoal++] = (uint32_t)ts;
     }
     if (kind == OC_DELIVER) h.goal_dl[g] |= 1u << s; else h.goal_nd[g] |= 1u << s;
@@ -1502,8 +1843,13 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
   for (uint32_t k = 0; k < h.ndeliv; k++) h.deliv_pos[k] = (uint32_t)(dl[2 * k] | (dl[2 * k + 1] << 4));
   // initial state words: OvercookedEnvironment.reset() (overcooked_environment.py:180-206)
   for (int a = 0; a < A; a++) h.init_words[a] = ag[2 * a] | (ag[2 * a + 1] << 4);
-  for (int i = 0; i < M; i++)
-    h.init_words[A + i] = it[3 * i + 1] | (it[3 * i + 2] << 4) | (i << 9) | (i << 16) | ((1 << it[3 * i]) << 24);
+  for (int i = 0; i < M; i++) {
+    int first = i;   // first item of the same type: its key is created when that one is inserted
+    while (first > 0 && it[3 * (first - 1)] == it[3 * i]) first--;
+    const int seqf = h.has_dup ? ((first << 4) | i) : i;
+    const int sigf = h.has_dup ? sig_of_type<true>(it[3 * i]) : sig_of_type<false>(it[3 * i]);
+    h.init_words[A + i] = it[3 * i + 1] | (it[3 * i + 2] << 4) | (i << 9) | (seqf << 16) | sigf;
+  }
   {
     int n_chop = 0, n_groups = (int)h.pair_static_max;
     for (int f = 0; f < 3; f++) n_chop += __builtin_popcount(h.chop_mask[f]);
@@ -1575,9 +1921,15 @@ int oc_level_spec_source(const int32_t *b, int32_t n_words, char *buf, int32_t b
   EMIT("  %uu,\n  %uu,\n", h.pair_static_max, h.ndeliv);
   EMIT_ARR(h.deliv_pos, OC_MAX_DELIV);
   EMIT("  {");
-  for (int k = 0; k < OC_MAX_AGENTS + OC_MAX_ITEMS + 2; k++) EMIT("%s%d", k ? ", " : "", h.init_words[k]);
+  for (int k = 0; k < OC_MAX_AGENTS + OC_MAX_ITEMS + 4; k++) EMIT("%s%d", k ? ", " : "", h.init_words[k]);
   EMIT("},\n  %uu,\n  %uu, %uu,\n", h.nquot, h.nscatter, h.ncounters);
   EMIT_ARR(h.scatter_item, 4);
+  EMIT("  %uu,\n", h.has_dup);
+  EMIT_ARR(h.goal_sig, MAX_GOALS);
+  EMIT_ARR(h.del_sig, MAX_DELS);
+  EMIT_ARR(h.food_items, 3);
+  EMIT("  %uu,\n", h.nnames);
+  EMIT_ARR(h.name_sig, MAX_NAMES);
   EMIT("};\n");
 #undef EMIT_ARR
 #undef EMIT
@@ -1612,7 +1964,9 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   // form (correctly rounded fp64 division, as CPython's int / int), then the u8 distances
   lv->quot_bytes = 0;   // (until round-1 v11: a table of fp64 quotients k / max_path came first)
   // ... then, in the last 64 bytes, the Counter tiles (x | y<<4) for random placement
-  const size_t bytes = (((size_t)lv->quot_bytes + (size_t)nc * nc + 15) & ~(size_t)15) + OC_MAX_COUNTERS;
+  // ... then (dup mode's set-order lookups) one u32 of probe slots per cell, 4 * OC_MAX_CELLS bytes
+  const size_t bytes = (((size_t)lv->quot_bytes + (size_t)nc * nc + 15) & ~(size_t)15) + 4 * OC_MAX_CELLS +
+                       OC_MAX_COUNTERS;
   lv->n16 = (int32_t)(bytes / 16);
   uint8_t *img = new (std::nothrow) uint8_t[bytes];
   if (!img) {
@@ -1621,6 +1975,22 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   }
   memset(img, 0, bytes);
   for (int i = 0; i < nc * nc; i++) img[lv->quot_bytes + i] = (uint8_t)dist[i];
+  {
+    uint32_t *pr = (uint32_t *)(img + bytes - OC_MAX_COUNTERS - 4 * OC_MAX_CELLS);
+    for (int c = 0; c < nc; c++) pr[c] = probe_code(c % h.W, c / h.W);
+    if (h.has_dup) {
+      // eight stored probes must place a third location whatever two slots are taken
+      for (int c = 0; c < nc; c++) {
+        uint32_t seen = 0;
+        for (int t = 0; t < 8; t++) seen |= 1u << ((pr[c] >> (3 * t)) & 7);
+        if (__builtin_popcount(seen) < 3) {
+          delete[] img;
+          delete lv;
+          return fail(OC_E_BADARG, "oc_level_create: a cell's set-table probe sequence is too short (dup mode)");
+        }
+      }
+    }
+  }
   {
     const int32_t *ct = b + b[OC_LV_OFF_COUNTERS];
     for (int k = 0; k < b[OC_LV_NCOUNTERS]; k++)
@@ -1647,7 +2017,9 @@ int oc_level_destroy(oc_level_t *lv) {
 }
 
 int64_t oc_metrics_slots(int64_t n) { return n <= 0 ? 0 : (n + 63) / 64; }
-int32_t oc_state_words(const oc_level_t *lv) { return lv ? lv->hdr.A + lv->hdr.M + 2 : 0; }
+int32_t oc_state_words(const oc_level_t *lv) {
+  return lv ? lv->hdr.A + lv->hdr.M + 2 + (lv->hdr.has_dup ? 2 : 0) : 0;
+}
 int32_t oc_obs_rows(const oc_level_t *lv, int32_t num_comm) {
   return lv ? 22 + lv->hdr.S + 2 * num_comm : 0;
 }
@@ -1660,7 +2032,8 @@ int oc_reset(const oc_level_t *lv, int32_t *state, const int32_t *mask, const in
     return fail(OC_E_BADARG, "oc_reset: this level places items at random; pass `placement` or `rng`");
   ResetArgs a{lv->hdr, lv->dev_tables, lv->n16, lv->quot_bytes, state, mask, placement, rng, n};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
-#define OC_X(AA, MM) return launch(k_reset<AA, MM>, a, n, stream, 0)
+  const bool D_ = lv->hdr.has_dup != 0;
+#define OC_X(AA, MM, DD) return launch(k_reset<AA, MM, DD>, a, n, stream, 0)
   OC_FOR_AM(OC_X)
 #undef OC_X
 }
@@ -1671,25 +2044,26 @@ int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_
   if (lv && n == 0) return OC_OK;
   if (!lv || !state || !actions || !reward || !done || !shaping || n < 0)
     return fail(OC_E_BADARG, "oc_step: bad argument");
-  if (!fits_buffer(n, lv->hdr.A + lv->hdr.M + 2, 4) || !fits_buffer(n, 2, 8))
+  if (!fits_buffer(n, oc_state_words(lv), 4) || !fits_buffer(n, 2, 8))
     return fail(OC_E_BADARG, "oc_step: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
   if (auto_reset && lv->hdr.nscatter > 0 && !placement && !rng)
     return fail(OC_E_BADARG, "oc_step: auto_reset on a random-placement level needs `placement` or `rng`");
   StepArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, actions, reward, done, shaping,
              metrics, placement, rng, n, auto_reset};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
+  const bool D_ = lv->hdr.has_dup != 0;
   const size_t lds = (size_t)lv->n16 * 16;
   if (tables_in_lds(n)) {
-#define OC_X(AA, MM) return launch_st(k_step<AA, MM, true, false>, a, n, stream, lds)
+#define OC_X(AA, MM, DD) return launch_st(k_step<AA, MM, true, false, DD>, a, n, stream, lds)
     OC_FOR_AM(OC_X)
 #undef OC_X
   } else {
     if (write_through(n)) {
-#define OC_X(AA, MM) return launch_st(k_step<AA, MM, false, true>, a, n, stream, 0)
+#define OC_X(AA, MM, DD) return launch_st(k_step<AA, MM, false, true, DD>, a, n, stream, 0)
       OC_FOR_AM(OC_X)
 #undef OC_X
     }
-#define OC_X(AA, MM) return launch_st(k_step<AA, MM, false, false>, a, n, stream, 0)
+#define OC_X(AA, MM, DD) return launch_st(k_step<AA, MM, false, false, DD>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   }
@@ -1704,21 +2078,22 @@ int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, cons
     return fail(OC_E_BADARG, "oc_obs: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
   ObsArgs a{lv->hdr, lv->run, state, comm, obs, timestep, n, *cfg};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
+  const bool D_ = lv->hdr.has_dup != 0;
   const bool wt = write_through(n);
   if (cfg->obs_int8 < 0 || cfg->obs_int8 > 2) return fail(OC_E_BADARG, "oc_obs: obs_int8 must be 0 (int32), 1 (int8) or 2 (float32)");
   if (cfg->obs_int8 == 1) {
-#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, 1, true>, a, n, stream, 0) \
-                                : launch(k_obs<AA, MM, 1, false>, a, n, stream, 0)
+#define OC_X(AA, MM, DD) return wt ? launch(k_obs<AA, MM, 1, true, DD>, a, n, stream, 0) \
+                                    : launch(k_obs<AA, MM, 1, false, DD>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   } else if (cfg->obs_int8 == 2) {
-#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, 2, true>, a, n, stream, 0) \
-                                : launch(k_obs<AA, MM, 2, false>, a, n, stream, 0)
+#define OC_X(AA, MM, DD) return wt ? launch(k_obs<AA, MM, 2, true, DD>, a, n, stream, 0) \
+                                    : launch(k_obs<AA, MM, 2, false, DD>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   } else {
-#define OC_X(AA, MM) return wt ? launch(k_obs<AA, MM, 0, true>, a, n, stream, 0) \
-                                : launch(k_obs<AA, MM, 0, false>, a, n, stream, 0)
+#define OC_X(AA, MM, DD) return wt ? launch(k_obs<AA, MM, 0, true, DD>, a, n, stream, 0) \
+                                    : launch(k_obs<AA, MM, 0, false, DD>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   }
@@ -1734,7 +2109,8 @@ int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int
     return fail(OC_E_BADARG, "oc_obs_image: n too large for one call; split the batch");
   ImageArgs a{lv->hdr, state, out, holding, n, radius};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
-#define OC_X(AA, MM) return launch(k_obs_image<AA, MM>, a, n, stream, 0)
+  const bool D_ = lv->hdr.has_dup != 0;
+#define OC_X(AA, MM, DD) return launch(k_obs_image<AA, MM, DD>, a, n, stream, 0)
   OC_FOR_AM(OC_X)
 #undef OC_X
 }
@@ -1742,11 +2118,17 @@ int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int
 int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
                   const oc_wrap_cfg *cfg, void *obs, double *timestep, double *reward, int32_t *done,
                   int32_t *sparse, int32_t auto_reset, int64_t *metrics, const int32_t *placement, uint32_t *rng,
-                  double *ep_return, int32_t *ep_length, int64_t n, void *stream) {
+                  const oc_step_opts *opts, int64_t n, void *stream) {
   if (lv && cfg && n == 0) return OC_OK;
-  if ((ep_return == nullptr) != (ep_length == nullptr))
+  oc_step_opts o;
+  memset(&o, 0, sizeof(o));
+  if (opts) o = *opts;
+  if ((o.ep_return == nullptr) != (o.ep_length == nullptr))
     return fail(OC_E_BADARG, "oc_multi_step: pass both ep_return and ep_length, or neither");
-  if (!lv || !state || !comm || !actions || !cfg || !obs || !timestep || !reward || !done || n < 0 ||
+  // the action rows may only be absent when both players' actions come from somewhere else
+  if (!actions && !(o.ego_pairs && (o.alt_pairs || o.alt_rng)))
+    return fail(OC_E_BADARG, "oc_multi_step: no `actions` and no complete replacement in `opts`");
+  if (!lv || !state || !comm || !cfg || !obs || !timestep || !reward || !done || n < 0 ||
       cfg->obs.num_comm < 0 || cfg->obs.num_comm > 128)
     return fail(OC_E_BADARG, "oc_multi_step: bad argument");
   if (lv->hdr.A != 2)
@@ -1756,31 +2138,44 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   if (auto_reset && lv->hdr.nscatter > 0 && !placement && !rng)
     return fail(OC_E_BADARG, "oc_multi_step: auto_reset on a random-placement level needs `placement` or `rng`");
   MultiArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, comm, actions, obs, timestep,
-              reward, done, sparse, metrics, placement, rng, ep_return, ep_length, n, auto_reset, *cfg};
+              reward, done, sparse, metrics, placement, rng, o, n, auto_reset, *cfg};
   const size_t lds = (size_t)lv->n16 * 16;
   const bool in_lds = tables_in_lds(n);
   const int ot = cfg->obs.obs_int8;   // 0 int32, 1 int8, 2 float32
   if (ot < 0 || ot > 2) return fail(OC_E_BADARG, "oc_multi_step: obs_int8 must be 0 (int32), 1 (int8) or 2 (float32)");
   const bool wt = write_through(n);
-#define OC_MS(MM)                                                                     \
+  const bool xo = o.ep_return || o.ego_pairs || o.alt_pairs || o.alt_rng;
+#define OC_MS_X(MM, DD, XX)                                                           \
   do {                                                                                \
-    if (in_lds && ot == 0) return launch_ms(k_multi_step<MM, true, 0, false>, a, n, stream, lds);      \
-    if (ot == 1) return wt ? launch_ms(k_multi_step<MM, false, 1, true>, a, n, stream, 0)              \
-                           : launch_ms(k_multi_step<MM, false, 1, false>, a, n, stream, 0);            \
-    if (ot == 2) return wt ? launch_ms(k_multi_step<MM, false, 2, true>, a, n, stream, 0)              \
-                           : launch_ms(k_multi_step<MM, false, 2, false>, a, n, stream, 0);            \
-    return wt ? launch_ms(k_multi_step<MM, false, 0, true>, a, n, stream, 0)                           \
-              : launch_ms(k_multi_step<MM, false, 0, false>, a, n, stream, 0);                         \
+    if (in_lds && ot == 0) return launch_ms(k_multi_step<MM, true, 0, false, DD, XX>, a, n, stream, lds);  \
+    if (ot == 1) return wt ? launch_ms(k_multi_step<MM, false, 1, true, DD, XX>, a, n, stream, 0)          \
+                           : launch_ms(k_multi_step<MM, false, 1, false, DD, XX>, a, n, stream, 0);        \
+    if (ot == 2) return wt ? launch_ms(k_multi_step<MM, false, 2, true, DD, XX>, a, n, stream, 0)          \
+                           : launch_ms(k_multi_step<MM, false, 2, false, DD, XX>, a, n, stream, 0);        \
+    return wt ? launch_ms(k_multi_step<MM, false, 0, true, DD, XX>, a, n, stream, 0)                       \
+              : launch_ms(k_multi_step<MM, false, 0, false, DD, XX>, a, n, stream, 0);                     \
+  } while (0)
+#define OC_MS(MM, DD)            \
+  do {                           \
+    if (xo) OC_MS_X(MM, DD, true); \
+    OC_MS_X(MM, DD, false);      \
   } while (0)
 #ifdef OC_SPECIALIZED
-  OC_MS(OC_SPEC_HDR.M);
+  OC_MS(OC_SPEC_HDR.M, OC_SPEC_DUP);
 #else
-  if (lv->hdr.M == 3) OC_MS(3);
-  if (lv->hdr.M == 4) OC_MS(4);
-  if (lv->hdr.M == 5) OC_MS(5);
+  if (lv->hdr.has_dup) {
+    if (lv->hdr.M == 3) OC_MS(3, true);
+    if (lv->hdr.M == 4) OC_MS(4, true);
+    if (lv->hdr.M == 5) OC_MS(5, true);
+  } else {
+    if (lv->hdr.M == 3) OC_MS(3, false);
+    if (lv->hdr.M == 4) OC_MS(4, false);
+    if (lv->hdr.M == 5) OC_MS(5, false);
+  }
   return fail(OC_E_BADARG, "oc_multi_step: unsupported number of items");
 #endif
 #undef OC_MS
+#undef OC_MS_X
 }
 
 int oc_random_actions(uint32_t *rng, int32_t *move_row, int32_t *comm_row, int32_t num_comm, int64_t n,

@@ -174,7 +174,7 @@ class OvercookedEnvironment:
         if words is None:                   # one column of the [A+M+2][n] state tensor
             i = self._index
             words = self._b.state[:, i:i + 1].cpu().numpy()
-        s = unpack_state(words, lv.num_agents, lv.num_items, lv.num_subtasks)
+        s = unpack_state(words, lv.num_agents, lv.num_items, lv.num_subtasks, **self._b.unpack_kw())
         self._v_t = int(s["t"][0])
         self._v_completed_subtasks = [int(v) for v in s["completed"][0]]
         self._v_goal_objects_count = [int(v) for v in s["goal_count"][0]]

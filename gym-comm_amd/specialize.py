@@ -18,6 +18,7 @@ import ctypes
 import hashlib
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -104,11 +105,12 @@ def ensure(blob, verbose=False):
     # several ranks may reach this point for the same level at once (one process per GPU):
     # every writer uses its own temporary names and publishes with an atomic rename
     hdr = os.path.join(SPEC_DIR, "spec_%s.h" % key)
-    tmp_hdr = "%s.%d.tmp" % (hdr, os.getpid())
+    uniq = "%d.%d" % (os.getpid(), threading.get_ident())   # ranks AND threads may build the same level at once
+    tmp_hdr = "%s.%s.tmp" % (hdr, uniq)
     with open(tmp_hdr, "w") as f:
         f.write(text)
     os.replace(tmp_hdr, hdr)
-    tmp_lib = "%s.%d.tmp" % (path, os.getpid())
+    tmp_lib = "%s.%s.tmp" % (path, uniq)
     cmd = [hipcc, "--offload-arch=" + _build.ARCH] + _build.FLAGS
     cmd += ["-DOC_SPECIALIZED", '-DOC_SPEC_FILE="%s"' % hdr]
     cmd += [os.path.join(_build.CSRC, s) for s in _build.SOURCES] + ["-o", tmp_lib]

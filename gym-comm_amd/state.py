@@ -2,13 +2,16 @@
 import numpy as np
 
 
-def unpack_state(words, A, M, S):
+def unpack_state(words, A, M, S, goal_index=None, deliver=None):
     """words: int array [A+M+2, n] (numpy).  Returns the canonical snapshot used by the
     golden fixtures and the oracle:
       items  [n][M][5]  x, y, state_index, group, holder agent (-1)
       order  [n][M]     groups in world.objects iteration order, -1 padded
       agents [n][A][3]  x, y, held group (-1)
       t, completed [n][S], goal_count [n][S], merge_counter, error
+    goal_index / deliver (per subtask: index of its distinct goal object, is-a-Deliver flag):
+    given for a level in dup mode, where the state keeps 2-bit counts per distinct goal; the
+    seq field of such a level is kseq<<4 | seq, still a world-order sort key.
     """
     w = np.asarray(words).astype(np.int64)
     n = w.shape[1]
@@ -25,11 +28,19 @@ def unpack_state(words, A, M, S):
     order = np.where(np.take_along_axis(is_rep, idx, axis=1), idx, -1)
     m0, m1 = w[A + M] & 0xFFFFFFFF, w[A + M + 1] & 0xFFFFFFFF
     bits = np.arange(S)
+    if goal_index is None:
+        goal_count = (m1[:, None] >> bits) & 1
+    else:
+        # dup mode (a level that repeats a content type): two bits per DISTINCT goal object;
+        # a Deliver subtask's own count is never updated by the reference (:404-415) and stays 0
+        gi = np.asarray(goal_index)
+        goal_count = (m1[:, None] >> (2 * gi)[None, :]) & 3
+        goal_count = np.where(np.asarray(deliver, bool)[None, :], 0, goal_count)
     return {
         "items": items.astype(np.int32), "order": order.astype(np.int32),
         "agents": agents.astype(np.int32), "t": ((w[0] >> 16) & 0xFFFF).astype(np.int32),
         "completed": ((m0[:, None] >> bits) & 1).astype(np.int32),
-        "goal_count": ((m1[:, None] >> bits) & 1).astype(np.int32),
+        "goal_count": goal_count.astype(np.int32),
         "merge_counter": ((w[1] >> 16) & 255).astype(np.int32),
         "error": ((w[1] >> 24) & 255).astype(np.int32),
         "nobj": is_rep.sum(axis=1).astype(np.int32),

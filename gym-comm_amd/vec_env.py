@@ -80,9 +80,12 @@ class ObsView(dict):
 
 
 class RandomPartner:
-    """Uniform random partner (move 0..3, comm 0..C-1): one launch of ``oc_random_actions``
-    (a PCG32 stream per env), written straight into the kernel's action rows."""
+    """Uniform random partner (move 0..3, comm 0..C-1) from a PCG32 stream per env.  In the
+    partner seat of an ``OvercookedVecEnv`` it costs NO launch: the fused step kernel draws the
+    actions itself (``oc_step_opts.alt_rng``, include/oc_hip.h) and reports them in action rows
+    2, 3.  Anywhere else (``act_into`` / call) it is one launch of ``oc_random_actions``."""
     graph_safe = True
+    in_kernel = True            # OvercookedVecEnv hands `rng_state(n)` to the step kernel
 
     def __init__(self, num_comm, seed=0, device="cuda"):
         self.C = int(num_comm)
@@ -90,6 +93,10 @@ class RandomPartner:
         self.device = torch.device(device)
         self._L = _lib.load()
         self._rng = None
+
+    def rng_state(self, n):
+        """int32 [n] tensor holding the n PCG32 states (uint32 bit patterns)."""
+        return self._state(n)
 
     def _state(self, n):
         if self._rng is None or self._rng.numel() != n:
@@ -213,38 +220,13 @@ class ClosedLoop:
             for pl in (ego, venv.partner):
                 if pl is not None and not getattr(pl, "graph_safe", False):
                     raise ValueError("%r is not marked graph_safe (stateless, fixed-shape)" % (pl,))
-            b = venv._b
-            # one eager warm-up step (module loads, rocBLAS workspaces) that must not count: the
-            # env's tensors, the action rows and every random stream are put back afterwards
-            players = [pl for pl in (ego, venv.partner) if pl is not None]
-            keep, act = b._arena.clone(), venv._act.clone()
-            rng = None if b.rng is None else b.rng.clone()
-            torch_rng = torch.cuda.get_rng_state(b.device)
-            saved = [pl.get_state(venv.num_envs) if hasattr(pl, "get_state") else None for pl in players]
-            ver = venv._version
-            self.enqueue()
-            torch.cuda.current_stream(b.device).synchronize()
-            b._arena.copy_(keep)
-            venv._act.copy_(act)
-            if rng is not None:
-                b.rng.copy_(rng)
-            torch.cuda.set_rng_state(torch_rng, b.device)
-            for pl, st in zip(players, saved):
-                if hasattr(pl, "set_state"):
-                    pl.set_state(st)
-            venv._version = ver
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                for _ in range(self.steps):
-                    self.enqueue()
-            venv._version = ver
+            self.graph = venv._capture(self.enqueue, players=[ego], repeat=self.steps)
 
     def enqueue(self):
         v = self.venv
         if self.ego is not None:
             self.ego.act_into(v._obs_tensors(0), v._act[0], v._act[1])
-        v.partner.act_into(v._obs_tensors(1), v._act[2], v._act[3])
-        v._b.multi_step(v._act)
+        v._partner_and_step(None)
         v._version += 1
 
     def step(self):
@@ -286,6 +268,7 @@ class OvercookedVecEnv(_VecEnvBase):
         lv = self._b.level
         obs_space, act_space = make_spaces(lv.width, lv.height, lv.num_subtasks, self._b.C)
         super().__init__(num_envs, obs_space, act_space)
+        self._fast = self._graph = None
         self.partner = partner if partner is not None else RandomPartner(self._b.C, seed, self._b.device)
         self._act = torch.zeros((4, num_envs), dtype=torch.int32, device=self._b.device)
         self._pending = None
@@ -299,7 +282,16 @@ class OvercookedVecEnv(_VecEnvBase):
         self._version = 0                                # bumped by every step / reset
         self._env_views = {}                             # env index -> (OvercookedEnvironment view, version)
         self._use_graph = bool(use_graph) and not self.terminal_obs
-        self._loop = None
+        self._ego_pairs = None
+
+    @property
+    def partner(self):
+        return self._partner
+
+    @partner.setter
+    def partner(self, pt):          # a new partner invalidates the prepared launch plan / captured graph
+        self._partner = pt
+        self._fast = self._graph = None
 
     # the running episode statistics live in the batch (kept by the kernel)
     @property
@@ -341,33 +333,122 @@ class OvercookedVecEnv(_VecEnvBase):
         """ego policy -> partner policy -> fused step as one hipGraph (see ``ClosedLoop``)."""
         return ClosedLoop(self, ego, graph=graph, steps=steps)
 
+    def _fast_plan(self):
+        """Addresses for the single-launch path of step_tensors, or False when it does not apply
+        (a partner with launches or an update() of its own, terminal_obs, a captured graph)."""
+        pt = self.partner
+        if self._use_graph or self.terminal_obs or not getattr(pt, "in_kernel", False) or hasattr(pt, "update"):
+            return False
+        return {"act": self._act.data_ptr(), "played": self._act[2:4].data_ptr(),
+                "rng": pt.rng_state(self.num_envs).data_ptr(), "obs": self._obs_tensors(0),
+                "pair_shape": torch.Size((self.num_envs, 2)), "dev": self._b._dev_index}
+
+    def _capture(self, fn, players=(), repeat=1):
+        """`repeat` calls of fn() as one hipGraph.  One eager warm-up call first (module loads,
+        rocBLAS workspaces) that must not count: the env's tensors, the action rows, the metrics
+        and every random stream (the env's, the players', torch's) are put back afterwards."""
+        b = self._b
+        if not getattr(self.partner, "graph_safe", False):
+            raise ValueError("%r is not marked graph_safe (stateless, fixed-shape)" % (self.partner,))
+        players = [pl for pl in list(players) + [self.partner] if pl is not None]
+        keep, act = b._arena.clone(), self._act.clone()
+        rng = None if b.rng is None else b.rng.clone()
+        met = None if b.metrics is None else b.metrics.clone()
+        torch_rng = torch.cuda.get_rng_state(b.device)
+        saved = [pl.get_state(self.num_envs) if hasattr(pl, "get_state") else None for pl in players]
+        ver = self._version
+        fn()
+        torch.cuda.current_stream(b.device).synchronize()
+        b._arena.copy_(keep)
+        self._act.copy_(act)
+        if rng is not None:
+            b.rng.copy_(rng)
+        if met is not None:
+            b.metrics.copy_(met)
+        torch.cuda.set_rng_state(torch_rng, b.device)
+        for pl, st in zip(players, saved):
+            if hasattr(pl, "set_state"):
+                pl.set_state(st)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(repeat):
+                fn()
+        self._version = ver
+        return graph
+
+    def _partner_and_step(self, ego_pairs, auto_reset=None):
+        """The partner's move and the fused step.  ego_pairs: the ego's int32 [n][2] (move, comm)
+        pairs, or None = rows 0, 1 of ``self._act``.  Launches: none for an in-kernel partner
+        (``RandomPartner``), the partner's own otherwise; then ONE for the step."""
+        b, pt = self._b, self.partner
+        if getattr(pt, "in_kernel", False):
+            b.multi_step(self._act, auto_reset=auto_reset, ego_pairs=ego_pairs,
+                         alt_rng=pt.rng_state(self.num_envs), alt_played=self._act[2:4])
+            return
+        partner_obs = self._obs_tensors(1)
+        alt_pairs = None
+        if hasattr(pt, "act_into"):     # rows of the action tensor: ego move, ego comm, alt move, alt comm
+            pt.act_into(partner_obs, self._act[2], self._act[3])
+        else:
+            pa = torch.as_tensor(pt(partner_obs), device=b.device)
+            if pa.dtype == torch.int32 and pa.is_contiguous():
+                alt_pairs = pa                               # consumed as it lies
+            else:
+                self._act[2:4].copy_(pa.T)
+        b.multi_step(self._act, auto_reset=auto_reset, ego_pairs=ego_pairs, alt_pairs=alt_pairs)
+
     def step_tensors(self, ego_actions=None):
         """ego_actions: int tensor [n, 2] on the device (None: already written into
-        ``ego_action_rows``).  Returns (ego obs dict of [n, k] tensors, shaped reward f64 [n],
+        ``ego_action_rows``).  A contiguous int32 tensor is handed to the kernel as it lies (no
+        copy, no extra launch).  Returns (ego obs dict of [n, k] tensors, shaped reward f64 [n],
         done int32 [n]) -- views that the next step overwrites."""
         b = self._b
+        f = self._fast
+        if f is None:
+            f = self._fast = self._fast_plan()
+        if f:   # one launch, no partner launch, nothing to capture: the per-call cost is one ctypes call
+            ego_ptr = None
+            if ego_actions is not None:
+                ea = ego_actions
+                if not (isinstance(ea, torch.Tensor) and ea.dtype is torch.int32 and ea.is_cuda
+                        and ea.is_contiguous() and ea.shape == f["pair_shape"] and ea.get_device() == f["dev"]):
+                    if self._ego_pairs is None:
+                        self._ego_pairs = torch.zeros(f["pair_shape"], dtype=torch.int32, device=b.device)
+                    self._ego_pairs.copy_(torch.as_tensor(ego_actions, device=b.device))
+                    ea = self._ego_pairs
+                ego_ptr = ea.data_ptr()
+            b.multi_step_raw(f["act"], ego_ptr, None, f["rng"], f["played"], 1)
+            self._version += 1
+            self._last_terminal = None
+            return f["obs"], b.shaped_reward, b.done
+        ego_pairs = None
         if ego_actions is not None:
-            self._act[0:2].copy_(torch.as_tensor(ego_actions, device=b.device).T)
-        partner_obs = self._obs_tensors(1)
+            ea = torch.as_tensor(ego_actions, device=b.device)
+            if ea.dtype == torch.int32 and ea.is_contiguous() and not self._use_graph:
+                ego_pairs = ea
+            else:                       # other dtypes / layouts, or the captured graph's fixed input
+                if self._ego_pairs is None:
+                    self._ego_pairs = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=b.device)
+                self._ego_pairs.copy_(ea)
+                ego_pairs = self._ego_pairs
         term = None
         if self._use_graph:
-            if self._loop is None:          # partner -> fused step, captured once
-                self._loop = ClosedLoop(self, None, graph=True)
-            self._loop.step()
+            if self._ego_pairs is None:
+                self._ego_pairs = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=b.device)
+            if ego_pairs is None:       # ego rows written by the caller: bring them into the graph's input
+                self._ego_pairs.copy_(self._act[0:2].T)
+            if self._graph is None:     # partner -> fused step, captured once
+                self._graph = self._capture(lambda: self._partner_and_step(self._ego_pairs))
+            self._graph.replay()
+            self._version += 1
         else:
-            # rows of the action tensor: ego move, ego comm, alt move, alt comm
-            if hasattr(self.partner, "act_into"):
-                self.partner.act_into(partner_obs, self._act[2], self._act[3])
-            else:
-                pa = torch.as_tensor(self.partner(partner_obs), device=b.device)
-                self._act[2:4].copy_(pa.T)
             if self.terminal_obs:
-                b.multi_step(self._act, auto_reset=False)
+                self._partner_and_step(ego_pairs, auto_reset=False)
                 term = {k: v.clone() for k, v in self._obs_tensors(0).items()}
                 b.reset(b.done)                                   # mask = done flags
                 b.observe()
             else:
-                b.multi_step(self._act)
+                self._partner_and_step(ego_pairs)
             self._version += 1
         rew, done = b.shaped_reward, b.done
         self._last_terminal = term

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 2
+#define OC_ABI_VERSION 3
 #define OC_API __attribute__((visibility("default")))
 
 enum {
@@ -84,6 +84,33 @@ typedef struct {
   int32_t ego_agent_idx;    /* OvercookedMultiEnv(ego_agent_idx=...) */
   int32_t can_move_mask;    /* bit0: ego_config["CAN_MOVE"], bit1: partner_config["CAN_MOVE"] */
 } oc_wrap_cfg;
+
+/* Optional device pointers of oc_multi_step (a HOST struct, read at the call; every field may
+ * be NULL):
+ *   ep_return double[n], ep_length int32[n] (both or neither): per-env episode statistics kept
+ *            by the kernel, what stable-baselines3's Monitor keeps around the reference's env
+ *            (trainer.py:87-121 -> info["episode"] = {"r", "l"}): an env whose `done` row was
+ *            set by the PREVIOUS step starts from zero, then the step's shaped reward / 1 is
+ *            added.  After a step that returns done they hold the finished episode's return
+ *            and length until the next step.  `done` must therefore be the same tensor from
+ *            step to step (zero it together with the statistics).
+ *   ego_pairs / alt_pairs  int32 [n][2]: a player's (move, comm) as an array of PAIRS -- the
+ *            batched form of multi_step's ego_action / alt_action tuples
+ *            (gym_comm/envs/overcooked_env.py:207-221), i.e. a policy's [n, 2] output as it
+ *            lies -- used instead of rows 0,1 / 2,3 of `actions`.
+ *   alt_rng  uint32 [n]: the partner plays uniformly at random (move 0..3, comm 0..C-1) from
+ *            this per-env PCG32 stream, advanced in place; rows 2,3 / alt_pairs are ignored.
+ *            No reference analogue (its partners are SB3 policies); the zero-launch partner
+ *            for throughput runs.  alt_played int32 [2][n], if given, receives what was drawn.
+ * `actions` may be NULL when ego_pairs and one of alt_pairs / alt_rng are given. */
+typedef struct {
+  double *ep_return;
+  int32_t *ep_length;
+  const int32_t *ego_pairs;
+  const int32_t *alt_pairs;
+  uint32_t *alt_rng;
+  int32_t *alt_played;
+} oc_step_opts;
 
 /* metrics accumulated by the step kernels when `metrics` != NULL: a device tensor
  * int64 [oc_metrics_slots(n)][8] -- one 64-byte slot per wave (64 envs); lanes 0..5 of the
@@ -175,17 +202,11 @@ OC_API int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radi
  *   comm     int32 [2][n]  in/out, persists across resets (:89-91,284-297)
  *   reward   double[n]     shaped reward, identical for both agents
  *   sparse   int32 [n] or NULL  the unshaped integer reward
- *   ep_return double[n], ep_length int32[n] (both or neither; NULL = off): per-env episode
- *            statistics kept by the kernel, what stable-baselines3's Monitor keeps around the
- *            reference's env (trainer.py:87-121 -> info["episode"] = {"r", "l"}): an env whose
- *            `done` row was set by the PREVIOUS step starts from zero, then the step's shaped
- *            reward / 1 is added.  After a step that returns done, ep_return / ep_length hold the
- *            finished episode's return and length until the next step.  `done` must therefore be
- *            the same tensor from step to step (zero it together with the statistics). */
+ *   opts     optional inputs / outputs, see oc_step_opts (NULL = none) */
 OC_API int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
                   const oc_wrap_cfg *cfg, void *obs, double *timestep, double *reward,
                   int32_t *done, int32_t *sparse, int32_t auto_reset, int64_t *metrics,
-                  const int32_t *placement, uint32_t *rng, double *ep_return, int32_t *ep_length,
+                  const int32_t *placement, uint32_t *rng, const oc_step_opts *opts,
                   int64_t n, void *stream);
 
 /* Uniform random (move, comm) indices for one player of every env, written straight into two

@@ -17,10 +17,8 @@ pytestmark = pytest.mark.gpu
 # rbase_/rwrap_: random-* levels; cbase_/cwrap_: our own maps run through the reference
 BASE = golden_files("base_") + golden_files("rbase_") + golden_files("cbase_")
 WRAP = golden_files("wrap_") + golden_files("rwrap_") + golden_files("cwrap_")
-DUP_PENDING = True      # the c*_dup_* fixtures (levels that repeat a content type): HIP support in progress
-if DUP_PENDING:
-    BASE = [p for p in BASE if "_dup_" not in p]
-    WRAP = [p for p in WRAP if "_dup_" not in p]
+# (c*_dup_*: maps that repeat a content type -- multiset objects, goal counts above 1, CPython's
+# set order in the shaping terms; the library's "dup" kernels)
 
 
 def _placement_tensor(lv, cells, n):
@@ -71,7 +69,7 @@ def test_base_step_matches_reference_golden(run):
     assert (Dn == z["done"][:, None]).all()
     assert (bits(Sh) == z["shaping_bits"][:, :, None]).all()
     for lane in (0, 63, 64, 95):
-        snap = unpack_state(S[:, :, lane].T, lv.num_agents, lv.num_items, lv.num_subtasks)
+        snap = unpack_state(S[:, :, lane].T, lv.num_agents, lv.num_items, lv.num_subtasks, **env.unpack_kw())
         assert (snap["items"] == z["items"][:, :, :5]).all(), lane
         assert (snap["order"] == z["order"]).all(), lane
         assert (snap["agents"] == z["agents"]).all(), lane
@@ -554,3 +552,65 @@ def test_error_flags_match_oracle(oracle_lib):
         assert oob > n // 2 and action > n // 4 and int(((prev & 2) != 0).sum()) == 0
         m = env.read_metrics()
         assert m["env_steps"] == n * steps and m["errors"] == raised
+
+
+DUP_SEEDED = [("cbase_dup_two_tomatoes_small_a2.npz", 2), ("cbase_dup_two_tomatoes_small_a3.npz", 3),
+              ("cbase_dup_two_lettuces_salad_a2.npz", 2), ("cbase_dup_two_tomatoes_a3.npz", 3)]
+
+
+@pytest.mark.parametrize("spec", [False, True], ids=["generic", "spec"])
+@pytest.mark.parametrize("name,A", DUP_SEEDED, ids=[c[0][10:-4] for c in DUP_SEEDED])
+def test_dup_levels_match_oracle_seeded(name, A, spec, oracle_lib):
+    """Levels that repeat a content type, every env with its own action stream, auto-reset on:
+    full state compare (multiset objects, world order by key creation, 2-bit goal counts), sparse
+    reward, done and raw shaping bits (the set-order `[0]`) against the oracle every step; for two
+    agents the fused wrapper step's observations as well."""
+    from hip_util import momentum_actions
+    z, st = load_golden(os.path.join(os.path.dirname(BASE[0]), name))
+    n, steps, T = 1500, 260, 90
+    from gym_comm_amd import compiler, levels
+    lv = compiler.compile_level(levels.parse_level_text(st["level"], st["level_text"]), A, T)
+    assert lv.has_dup
+    rng = np.random.default_rng(31 + A)
+    acts = momentum_actions(rng, steps, A, n, keep=0.6)
+    ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
+    env = _env(lv, n, auto_reset=True, specialize_level=spec)
+    assert env.kernel_flavour == ("spec" if spec else "generic") and env.W_state == A + lv.num_items + 4
+    acts_d = torch.from_numpy(acts).cuda()
+    tot_r = above1 = merges = flagged = 0
+    for k in range(steps):
+        r, d, sh = env.step(acts_d[k])
+        ro, do, sho = ora.step(acts[k], auto_reset=True)
+        hs, os_ = env.snapshot(), ora.snapshot_all()
+        ctx = "%s step %d" % (name, k)
+        # the same flags on the same envs; a flagged env (three agents, two of them on one cell
+        # holding same-named objects while one merges: World.remove takes the wrong one and the
+        # reference's store is corrupt from there) is left out until its episode ends
+        assert np.array_equal(hs["error"], os_["error"]), ctx
+        clean = os_["error"] == 0
+        flagged += int((~clean).sum())
+        assert np.array_equal(r.cpu().numpy()[clean], ro[clean]), ctx
+        assert np.array_equal(d.cpu().numpy()[clean], do[clean]), ctx
+        assert np.array_equal(bits(sh.cpu().numpy())[:, clean], bits(sho)[:, clean]), ctx
+        assert_snapshots_equal(hs, os_, ctx, where=clean)
+        tot_r += int(ro.sum())
+        above1 += int((os_["goal_count"] > 1).any(axis=1).sum())
+        merges += int((os_["nobj"] < lv.num_items).sum())
+    assert tot_r > 0 and above1 > 0 and merges > 0, (tot_r, above1, merges)
+    # exact flagged fraction (counted with the oracle on the CPU): env-steps spent flagged, of 390 000
+    assert flagged == {"cbase_dup_two_tomatoes_small_a3.npz": 72}.get(name, 0), flagged
+    if A == 2:
+        C, radius = 3, 1
+        ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
+        env = _env(lv, n, auto_reset=True, specialize_level=spec, num_communication=C, fow_radius=radius)
+        comm = np.zeros((2, n), np.int32)
+        mv = np.minimum(acts, 3)
+        cm = rng.integers(0, C, (steps, 2, n)).astype(np.int32)
+        for k in range(steps):
+            a = np.stack([mv[k, 0], cm[k, 0], mv[k, 1], cm[k, 1]]).astype(np.int32)
+            o, t, r, d = env.multi_step(torch.from_numpy(a).cuda())
+            oo, to, ro, do = ora.multi_step(a, comm, radius, 0, C, auto_reset=True)
+            ctx = "%s fused step %d" % (name, k)
+            assert np.array_equal(d.cpu().numpy(), do), ctx
+            assert np.array_equal(bits(r.cpu().numpy()), bits(ro)), ctx
+            assert np.array_equal(o.cpu().numpy(), oo), ctx

@@ -97,7 +97,7 @@ def test_c_abi_exports_every_declared_symbol():
     L = _lib.load()
     for sym in declared:
         assert getattr(L, sym) is not None
-    assert L.oc_abi_version() == _lib.ABI_VERSION == 2
+    assert L.oc_abi_version() == _lib.ABI_VERSION == 3
     # argument validation happens before any device work
     assert L.oc_step(None, None, None, None, None, None, 0, None, None, None, 0, None) == -1
     assert b"oc_step" in L.oc_last_error()
@@ -222,13 +222,21 @@ def test_level_validation_happens_before_any_device_work():
     ok = C.compile_level("open-divider_tomato", 2, 100)
     rc, msg = _create(lib, ok.blob)
     assert rc == (0 if torch.cuda.is_available() else -2), msg
-    # two tomatoes: the HIP path keys an object by its type SET
-    spec = L.load_level("open-divider_tomato")
-    spec.map_items.append((L.TOMATO, 6, 2))
-    two = C.compile_level(spec, 2, 100)
-    assert not two.hip_supported
+    # a level that repeats a food type runs in the library's "dup" mode (multiset objects, two
+    # more state words): no rejection; four of one type exceed the packed item words
+    two = C.compile_level(L.parse_level_text(
+        "two-tomatoes", "-t---t-\n/     l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSimpleTomato\n\n2 1\n4 1"), 2, 100)
+    assert two.has_dup and two.hip_supported and not ok.has_dup
+    assert len(two.goal_index) == 3 and len(set(two.goal_index)) == 2
     rc, msg = _create(lib, two.blob)
-    assert rc == -1 and "twice" in msg
+    assert rc == (0 if torch.cuda.is_available() else -2), msg
+    from gym_comm_amd import specialize
+    assert "OC_SPEC_HDR" in specialize.spec_header_text(two.blob)
+    four = C.compile_level(L.parse_level_text(
+        "four-tomatoes", "-t-t-t-\n/     t\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSimpleTomato\n\n2 1\n4 1"), 2, 100)
+    assert not four.hip_supported
+    rc, msg = _create(lib, four.blob)
+    assert rc == -1 and "three" in msg
     bad = ok.blob.copy(); bad[4] = 1                       # one agent
     assert _create(lib, bad)[0] == -1
     bad = ok.blob.copy(); bad[23] += 1                     # wrong total length

@@ -193,7 +193,7 @@ def test_closed_loop_with_torch_policies(sample, oracle_lib):
         ep_ret = np.where(prev_done != 0, ro, ep_ret + ro)
         assert np.array_equal(venv.episode_returns.cpu().numpy().view(np.uint64), ep_ret.view(np.uint64)), k
         prev_done = do.copy()
-    assert len(seen) > 1                              # the policy is not a constant
+    assert len(seen) > 1 or not sample                # sampled actions vary (an argmax policy may be constant)
     assert venv.metrics()["env_steps"] == n * K and venv.metrics()["episodes"] >= n * (K // T)
 
 
