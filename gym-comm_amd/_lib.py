@@ -32,7 +32,8 @@ class StepOpts(ctypes.Structure):
     """oc_step_opts (include/oc_hip.h): optional device pointers of oc_multi_step."""
     _fields_ = [("ep_return", ctypes.c_void_p), ("ep_length", ctypes.c_void_p),
                 ("ego_pairs", ctypes.c_void_p), ("alt_pairs", ctypes.c_void_p),
-                ("alt_rng", ctypes.c_void_p), ("alt_played", ctypes.c_void_p)]
+                ("alt_rng", ctypes.c_void_p), ("alt_played", ctypes.c_void_p),
+                ("pairs_int64", ctypes.c_int32)]
 
 
 class OcError(RuntimeError):

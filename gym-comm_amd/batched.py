@@ -209,7 +209,7 @@ class BatchedOvercooked:
                    alt_rng: Optional[torch.Tensor] = None, alt_played: Optional[torch.Tensor] = None):
         """gym_comm wrapper step in one launch.  actions: int32 [4][n] = ego move (0..3),
         ego comm, alt move, alt comm.  Per player the (move, comm) may instead come as an
-        int32 [n][2] tensor of pairs (`ego_pairs` / `alt_pairs`: a policy's [n, 2] output as it
+        int32 or int64 [n][2] tensor of pairs (`ego_pairs` / `alt_pairs`: a policy's [n, 2] output as it
         lies), and the partner may be drawn by the kernel itself, uniformly, from a per-env
         PCG32 stream (`alt_rng`, int32/uint32 [n]; `alt_played` int32 [2][n] receives the draw)
         -- include/oc_hip.h, oc_step_opts.  Returns (obs, timestep, shaped_reward f64[n], done)."""
@@ -218,33 +218,38 @@ class BatchedOvercooked:
             self._check_tensor(actions, (4, n), torch.int32, "actions")
         elif ego_pairs is None or (alt_pairs is None and alt_rng is None):
             raise ValueError("multi_step needs `actions`, or `ego_pairs` and one of `alt_pairs` / `alt_rng`")
-        if ego_pairs is not None:
-            self._check_tensor(ego_pairs, (n, 2), torch.int32, "ego_pairs")
-        if alt_pairs is not None:
-            self._check_tensor(alt_pairs, (n, 2), torch.int32, "alt_pairs")
+        pdt = None
+        for name, t in (("ego_pairs", ego_pairs), ("alt_pairs", alt_pairs)):
+            if t is not None:
+                if t.dtype not in (torch.int32, torch.int64) or (pdt is not None and t.dtype != pdt):
+                    raise ValueError("ego_pairs / alt_pairs must be int32 or int64, both the same")
+                pdt = t.dtype
+                self._check_tensor(t, (n, 2), pdt, name)
         if alt_rng is not None:
             self._check_tensor(alt_rng, (n,), torch.int32, "alt_rng")
         if alt_played is not None:
             self._check_tensor(alt_played, (2, n), torch.int32, "alt_played")
         ptr = lambda t: None if t is None else t.data_ptr()
         self.multi_step_raw(ptr(actions) or 0, ptr(ego_pairs), ptr(alt_pairs), ptr(alt_rng), ptr(alt_played),
-                            int(self.auto_reset if auto_reset is None else auto_reset))
+                            int(self.auto_reset if auto_reset is None else auto_reset), pdt is torch.int64)
         return self.obs, self.timestep, self.shaped_reward, self.done
 
-    def multi_step_raw(self, actions_ptr, ego_pairs_ptr, alt_pairs_ptr, alt_rng_ptr, alt_played_ptr, auto_reset):
+    def multi_step_raw(self, actions_ptr, ego_pairs_ptr, alt_pairs_ptr, alt_rng_ptr, alt_played_ptr, auto_reset,
+                       pairs_int64=False):
         """multi_step on raw device addresses (int, None = absent), nothing checked: the per-call
         cost is one ctypes call.  For callers that validated their tensors once (vec_env)."""
         a = self._ms_args
         if a is None:       # every pointer but the action sources is fixed for the life of the env
             dp = lambda t: 0 if t is None else t.data_ptr()
             self._ms_opts = _lib.StepOpts(dp(self.ep_return) or None, dp(self.ep_length) or None,
-                                          None, None, None, None)
+                                          None, None, None, None, 0)
             a = self._ms_args = [self._h, dp(self.state), dp(self.comm), 0, ctypes.byref(self._wrap_cfg),
                                  dp(self.obs), dp(self.timestep), dp(self.shaped_reward), dp(self.done),
                                  dp(self.reward), 0, dp(self.metrics), dp(self.placement), dp(self.rng),
                                  ctypes.byref(self._ms_opts), self.n, 0]
         o = self._ms_opts
         o.ego_pairs, o.alt_pairs, o.alt_rng, o.alt_played = ego_pairs_ptr, alt_pairs_ptr, alt_rng_ptr, alt_played_ptr
+        o.pairs_int64 = 1 if pairs_int64 else 0
         a[3] = actions_ptr
         a[10] = auto_reset
         a[16] = self._raw_stream()

@@ -1462,7 +1462,7 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   const int i = (int)blockIdx.x * (block_ & 0xFFFF) + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
   const bool valid = i < (int)n_;
   const bool ego_from_pairs = XO && ((block_ >> 16) & 1), alt_from_pairs = XO && ((block_ >> 17) & 1),
-             alt_from_rng = XO && ((block_ >> 18) & 1);
+             alt_from_rng = XO && ((block_ >> 18) & 1), pairs64 = XO && ((block_ >> 19) & 1);
 #ifdef OC_STAMPS
   unsigned long long oc_tt[16];
   for (int k = 0; k < 16; k++) oc_tt[k] = 0;
@@ -1488,7 +1488,12 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     // uniformly from the env's own PCG32 stream (oc_step_opts).  All three tests are uniform.
     typedef int v2i __attribute__((ext_vector_type(2)));
     int ego_mv, ego_cm, alt_mv, alt_cm;
-    if (ego_from_pairs) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    if (ego_from_pairs && pairs64) {   // int64 pairs (a torch argmax / sample as it comes): the low words
+      const Rows pr(p.opt.ego_pairs, n_, 1, i, 16);
+      const v4i q = (v4i)__builtin_amdgcn_raw_buffer_load_b128(pr.rsrc, pr.voff, 0, 0);
+      ego_mv = (q.y == (q.x >> 31)) ? q.x : -1, ego_cm = (q.w == (q.z >> 31)) ? q.z : -1;   // outside int32: invalid
+    } else if (ego_from_pairs) {
       const Rows pr(p.opt.ego_pairs, n_, 1, i, 8);
       const v2i q = (v2i)__builtin_amdgcn_raw_buffer_load_b64(pr.rsrc, pr.voff, 0, 0);
       ego_mv = q.x, ego_cm = q.y;
@@ -1506,6 +1511,10 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
         ap.st(0, alt_mv);
         ap.st(1, alt_cm);
       }
+    } else if (alt_from_pairs && pairs64) {
+      const Rows pr(p.opt.alt_pairs, n_, 1, i, 16);
+      const v4i q = (v4i)__builtin_amdgcn_raw_buffer_load_b128(pr.rsrc, pr.voff, 0, 0);
+      alt_mv = (q.y == (q.x >> 31)) ? q.x : -1, alt_cm = (q.w == (q.z >> 31)) ? q.z : -1;
     } else if (alt_from_pairs) {
       const Rows pr(p.opt.alt_pairs, n_, 1, i, 8);
       const v2i q = (v2i)__builtin_amdgcn_raw_buffer_load_b64(pr.rsrc, pr.voff, 0, 0);
@@ -1645,7 +1654,8 @@ int launch_st(K kernel, const StepArgs &a, int64_t n, void *stream, size_t lds_b
 }
 template <typename K>
 int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
-  const int32_t src = (a.opt.ego_pairs ? 1 : 0) | (a.opt.alt_pairs ? 2 : 0) | (a.opt.alt_rng ? 4 : 0);
+  const int32_t src = (a.opt.ego_pairs ? 1 : 0) | (a.opt.alt_pairs ? 2 : 0) | (a.opt.alt_rng ? 4 : 0) |
+                      (a.opt.pairs_int64 ? 8 : 0);
   return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.comm, a.metrics, a.n,
                   (int32_t)(block_size_for(n) | (src << 16)), a);
 }
@@ -2133,7 +2143,7 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
     return fail(OC_E_BADARG, "oc_multi_step: bad argument");
   if (lv->hdr.A != 2)
     return fail(OC_E_BADARG, "oc_multi_step: the gym_comm wrapper drives exactly 2 agents");
-  if (!fits_buffer(n, 2 * (22 + lv->hdr.S + 2 * cfg->obs.num_comm), 4))
+  if (!fits_buffer(n, 2 * (22 + lv->hdr.S + 2 * cfg->obs.num_comm), 4) || !fits_buffer(n, 1, 16))
     return fail(OC_E_BADARG, "oc_multi_step: n too large for one call (tensor rows are addressed with 32-bit offsets); split the batch");
   if (auto_reset && lv->hdr.nscatter > 0 && !placement && !rng)
     return fail(OC_E_BADARG, "oc_multi_step: auto_reset on a random-placement level needs `placement` or `rng`");

@@ -399,8 +399,8 @@ class OvercookedVecEnv(_VecEnvBase):
 
     def step_tensors(self, ego_actions=None):
         """ego_actions: int tensor [n, 2] on the device (None: already written into
-        ``ego_action_rows``).  A contiguous int32 tensor is handed to the kernel as it lies (no
-        copy, no extra launch).  Returns (ego obs dict of [n, k] tensors, shaped reward f64 [n],
+        ``ego_action_rows``).  A contiguous int32 or int64 tensor is handed to the kernel as it
+        lies (no copy, no extra launch).  Returns (ego obs dict of [n, k] tensors, shaped reward f64 [n],
         done int32 [n]) -- views that the next step overwrites."""
         b = self._b
         f = self._fast
@@ -410,14 +410,16 @@ class OvercookedVecEnv(_VecEnvBase):
             ego_ptr = None
             if ego_actions is not None:
                 ea = ego_actions
-                if not (isinstance(ea, torch.Tensor) and ea.dtype is torch.int32 and ea.is_cuda
-                        and ea.is_contiguous() and ea.shape == f["pair_shape"] and ea.get_device() == f["dev"]):
+                if not (isinstance(ea, torch.Tensor) and (ea.dtype is torch.int32 or ea.dtype is torch.int64)
+                        and ea.is_cuda and ea.is_contiguous() and ea.shape == f["pair_shape"]
+                        and ea.get_device() == f["dev"]):
                     if self._ego_pairs is None:
                         self._ego_pairs = torch.zeros(f["pair_shape"], dtype=torch.int32, device=b.device)
                     self._ego_pairs.copy_(torch.as_tensor(ego_actions, device=b.device))
                     ea = self._ego_pairs
                 ego_ptr = ea.data_ptr()
-            b.multi_step_raw(f["act"], ego_ptr, None, f["rng"], f["played"], 1)
+                i64 = ea.dtype is torch.int64
+            b.multi_step_raw(f["act"], ego_ptr, None, f["rng"], f["played"], 1, ego_ptr is not None and i64)
             self._version += 1
             self._last_terminal = None
             return f["obs"], b.shaped_reward, b.done
@@ -425,7 +427,7 @@ class OvercookedVecEnv(_VecEnvBase):
         if ego_actions is not None:
             ea = torch.as_tensor(ego_actions, device=b.device)
             if ea.dtype == torch.int32 and ea.is_contiguous() and not self._use_graph:
-                ego_pairs = ea
+                ego_pairs = ea                 # (the slow path keeps to int32: alt_pairs may join it)
             else:                       # other dtypes / layouts, or the captured graph's fixed input
                 if self._ego_pairs is None:
                     self._ego_pairs = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=b.device)

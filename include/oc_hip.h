@@ -94,10 +94,11 @@ typedef struct {
  *            added.  After a step that returns done they hold the finished episode's return
  *            and length until the next step.  `done` must therefore be the same tensor from
  *            step to step (zero it together with the statistics).
- *   ego_pairs / alt_pairs  int32 [n][2]: a player's (move, comm) as an array of PAIRS -- the
- *            batched form of multi_step's ego_action / alt_action tuples
- *            (gym_comm/envs/overcooked_env.py:207-221), i.e. a policy's [n, 2] output as it
- *            lies -- used instead of rows 0,1 / 2,3 of `actions`.
+ *   ego_pairs / alt_pairs  int32 [n][2] (int64 [n][2] when pairs_int64 != 0): a player's
+ *            (move, comm) as an array of PAIRS -- the batched form of multi_step's ego_action /
+ *            alt_action tuples (gym_comm/envs/overcooked_env.py:207-221), i.e. a policy's [n, 2]
+ *            output as it lies (torch's argmax / sampling give int64) -- used instead of rows
+ *            0,1 / 2,3 of `actions`.
  *   alt_rng  uint32 [n]: the partner plays uniformly at random (move 0..3, comm 0..C-1) from
  *            this per-env PCG32 stream, advanced in place; rows 2,3 / alt_pairs are ignored.
  *            No reference analogue (its partners are SB3 policies); the zero-launch partner
@@ -110,6 +111,7 @@ typedef struct {
   const int32_t *alt_pairs;
   uint32_t *alt_rng;
   int32_t *alt_played;
+  int32_t pairs_int64;
 } oc_step_opts;
 
 /* metrics accumulated by the step kernels when `metrics` != NULL: a device tensor

@@ -614,3 +614,53 @@ def test_dup_levels_match_oracle_seeded(name, A, spec, oracle_lib):
             assert np.array_equal(d.cpu().numpy(), do), ctx
             assert np.array_equal(bits(r.cpu().numpy()), bits(ro)), ctx
             assert np.array_equal(o.cpu().numpy(), oo), ctx
+
+
+def test_action_sources_agree(oracle_lib):
+    """oc_step_opts: the same (move, comm) actions as rows of `actions`, as int32 [n][2] pairs and
+    as int64 [n][2] pairs give identical steps; an int64 value outside int32 is an invalid index
+    (OC_ERR_ACTION); a partner drawn in-kernel (alt_rng) plays exactly what oc_random_actions
+    draws from the same PCG32 states, and reports it in alt_played."""
+    import ctypes
+    from gym_comm_amd import compiler, _lib
+    lv = compiler.compile_level("open-divider_salad", 2, 60)
+    n, steps, C = 1111, 90, 4
+    rng = np.random.default_rng(17)
+    mv = rng.integers(0, 4, (steps, 2, n)).astype(np.int32)
+    cm = rng.integers(0, C, (steps, 2, n)).astype(np.int32)
+    envs = [_env(lv, n, num_communication=C, fow_radius=1, auto_reset=True) for _ in range(4)]
+    seeds = torch.randint(0, 2 ** 31 - 1, (n,), dtype=torch.int64).to(torch.int32).cuda()
+    r_kernel, r_lib = seeds.clone(), seeds.clone()
+    played = torch.zeros((2, n), dtype=torch.int32, device="cuda")
+    L = _lib.load()
+    for k in range(steps):
+        rows = torch.from_numpy(np.stack([mv[k, 0], cm[k, 0], mv[k, 1], cm[k, 1]])).cuda()
+        ego32 = torch.from_numpy(np.stack([mv[k, 0], cm[k, 0]], axis=1).copy()).cuda()
+        alt32 = torch.from_numpy(np.stack([mv[k, 1], cm[k, 1]], axis=1).copy()).cuda()
+        out = [envs[0].multi_step(rows),
+               envs[1].multi_step(None, ego_pairs=ego32, alt_pairs=alt32),
+               envs[2].multi_step(rows, ego_pairs=ego32.long())]           # int64 ego pairs + partner rows
+        ref = [t.clone() for t in out[0]]
+        for o in out[1:]:
+            for a, b in zip(ref, o):
+                assert torch.equal(a, b), k
+        assert torch.equal(envs[0].state, envs[1].state) and torch.equal(envs[0].state, envs[2].state), k
+        # in-kernel random partner == the library's generator kernel on the same states
+        envs[3].multi_step(None, ego_pairs=ego32, alt_rng=r_kernel, alt_played=played)
+        exp = torch.zeros((2, n), dtype=torch.int32, device="cuda")
+        vp = ctypes.c_void_p
+        assert L.oc_random_actions(vp(r_lib.data_ptr()), vp(exp[0].data_ptr()), vp(exp[1].data_ptr()), C, n,
+                                   vp(torch.cuda.current_stream().cuda_stream)) == 0
+        assert torch.equal(played, exp) and torch.equal(r_kernel, r_lib), k
+        assert int(played[0].max()) <= 3 and int(played[1].max()) < C
+    assert envs[3].read_metrics()["env_steps"] == n * steps
+    # int64 values that do not fit int32 are invalid indices, not truncated ones
+    e = _env(lv, n, num_communication=C, auto_reset=False)
+    big = torch.zeros((n, 2), dtype=torch.int64, device="cuda")
+    big[::3, 0] = (1 << 32) + 1                     # low word 1 = a valid move, were it truncated
+    big[1::3, 1] = -(1 << 40)
+    e.multi_step(None, ego_pairs=big, alt_pairs=torch.zeros((n, 2), dtype=torch.int64, device="cuda"))
+    err = e.snapshot()["error"]
+    assert (err[::3] == 4).all() and (err[1::3] == 4).all() and (err[2::3] == 0).all()
+    with pytest.raises(ValueError):
+        e.multi_step(None, ego_pairs=big)           # no source for the partner

@@ -28,7 +28,7 @@ def main():
                               ego_config={}, partner_config={}, num_communication=2,
                               communication_on=True, ego_led=False, fow_radius=2)
         gen = torch.Generator(device="cuda").manual_seed(0)
-        acts = [torch.stack([torch.randint(0, 4, (n,), generator=gen, device="cuda"),
+        acts = [torch.stack([torch.randint(0, 4, (n,), generator=gen, device="cuda"),   # int64, as a policy gives them
                              torch.randint(0, 2, (n,), generator=gen, device="cuda")], dim=1)
                 for _ in range(64)]
         for use_graph in (False, True):
