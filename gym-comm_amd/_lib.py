@@ -12,7 +12,7 @@ _I32P = ctypes.POINTER(ctypes.c_int32)
 ABI_VERSION = 3          # include/oc_hip.h: OC_ABI_VERSION
 
 SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destroy",
-           "oc_level_spec_source", "oc_is_specialized",
+           "oc_level_spec_source", "oc_is_specialized", "oc_level_subtask_info",
            "oc_metrics_slots", "oc_state_words", "oc_obs_rows", "oc_reset", "oc_step", "oc_obs",
            "oc_obs_image", "oc_image_words", "oc_multi_step", "oc_random_actions"]
 
@@ -67,6 +67,7 @@ def _declare(L):
     L.oc_level_create.argtypes = [_I32P, ctypes.c_int32, ctypes.POINTER(vp)]
     L.oc_level_destroy.argtypes = [vp]
     L.oc_level_spec_source.argtypes = [_I32P, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
+    L.oc_level_subtask_info.argtypes = [_I32P, ctypes.c_int32, _I32P, _I32P, _I32P]
     L.oc_metrics_slots.argtypes = [ctypes.c_int64]
     L.oc_metrics_slots.restype = ctypes.c_int64
     L.oc_state_words.argtypes = [vp]
@@ -82,7 +83,8 @@ def _declare(L):
     L.oc_multi_step.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
                                 ctypes.c_int32, vp, vp, vp, ctypes.POINTER(StepOpts), ctypes.c_int64, vp]
     L.oc_random_actions.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
-    for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_reset", "oc_step",
+    for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_level_subtask_info",
+              "oc_reset", "oc_step",
               "oc_obs", "oc_obs_image", "oc_multi_step", "oc_random_actions"):
         getattr(L, f).restype = ctypes.c_int
     if L.oc_abi_version() != ABI_VERSION:
@@ -110,3 +112,17 @@ def check(rc, what, lib=None):
     if rc != 0:
         msg = (lib or load()).oc_last_error()
         raise OcError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def subtask_info(blob, lib=None):
+    """(slot, goal_index, dup) of a level blob (include/oc_hip.h: oc_level_subtask_info): where the
+    state tensor keeps the bits of the blob's subtask s.  Host only."""
+    import numpy as np
+    L = lib or load()
+    blob = np.ascontiguousarray(blob, dtype=np.int32)
+    S = int(blob[6])
+    slot, gi = np.zeros(S, np.int32), np.zeros(S, np.int32)
+    dup = ctypes.c_int32()
+    check(L.oc_level_subtask_info(blob.ctypes.data_as(_I32P), int(blob.size), slot.ctypes.data_as(_I32P),
+                                  gi.ctypes.data_as(_I32P), ctypes.byref(dup)), "oc_level_subtask_info", L)
+    return slot.tolist(), gi.tolist(), bool(dup.value)

@@ -74,6 +74,8 @@ class BatchedOvercooked:
             _lib.check(self._L.oc_level_create(blob.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                                int(blob.size), ctypes.byref(h)), "oc_level_create", self._L)
         self._h = h
+        # where the state keeps the bits of subtask s (the library's canonical subtask order)
+        self.subtask_slot, self._goal_index, self._dup = _lib.subtask_info(blob, self._L)
         self.W_state = self._L.oc_state_words(h)
         self.F = self._L.oc_obs_rows(h, self.C)
         n = self.n
@@ -288,8 +290,9 @@ class BatchedOvercooked:
     def completed_subtasks(self):
         """completed_subtasks of every env as int32 [S][n] (from the packed state)."""
         word = self.state[self.A + self.M]
-        bits = torch.arange(self.S, device=self.device, dtype=torch.int32).view(-1, 1)
-        return (word.view(1, -1) >> bits) & 1
+        if getattr(self, "_slot_t", None) is None:
+            self._slot_t = torch.tensor(self.subtask_slot, device=self.device, dtype=torch.int32).view(-1, 1)
+        return (word.view(1, -1) >> self._slot_t) & 1
 
     def obs_dict(self, viewer: int):
         """The 11 observation keys of get_observation2 as tensor views: key -> [k][n]
@@ -304,11 +307,13 @@ class BatchedOvercooked:
         return unpack_state(self.state.cpu().numpy(), self.A, self.M, self.S, **self.unpack_kw())
 
     def unpack_kw(self):
-        """Extra arguments state.unpack_state needs for this level (dup mode only)."""
-        lv = self.level
-        if not lv.has_dup:
-            return {}
-        return {"goal_index": lv.goal_index, "deliver": [s.kind == compiler.KIND_DELIVER for s in lv.subtasks]}
+        """Extra arguments state.unpack_state needs for this level: the bit of every subtask in
+        the state's subtask words and, in dup mode, where its goal count lives."""
+        kw = {"slot": self.subtask_slot}
+        if self._dup:
+            kw.update(goal_index=self._goal_index,
+                      deliver=[s.kind == compiler.KIND_DELIVER for s in self.level.subtasks])
+        return kw
 
     def fetch(self):
         """ONE device->host copy of everything a step produced: returns {name: numpy view}

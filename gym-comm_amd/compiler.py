@@ -237,12 +237,15 @@ def canonical_subtasks(recipes: Sequence[str], item_types: Sequence[int],
     """Subtasks of all recipes, flattened recipe by recipe
     (overcooked_environment.py:456-457).  Within a recipe the reference's order is
     ``set`` iteration order, i.e. it changes with PYTHONHASHSEED; ours is Chop <
-    Merge < Deliver, then by args."""
+    Merge < Deliver, then by goal object, then by args."""
     out = []
     for r in recipes:
-        acts = plan_subtasks(r, item_types, max_path_length)
-        acts.sort(key=lambda a: (_KIND_RANK[a.kind], a.args))
-        out.extend(_subtask_from_action(a) for a in acts)
+        subs = [_subtask_from_action(a) for a in plan_subtasks(r, item_types, max_path_length)]
+        # (kind, goal object, food) is also how the HIP library orders subtask bits internally
+        # (include/oc_hip.h: oc_level_subtask_info), so for a one-recipe level the canonical
+        # order needs no permutation on the device
+        subs.sort(key=lambda t: (t.kind, t.goal_sig, t.food, t.args))
+        out.extend(subs)
     return out
 
 
@@ -399,17 +402,6 @@ class CompiledLevel:
         if len([t for t in types if t != L.PLATE]) != len({t for t in types if t != L.PLATE}):
             return True
         return any(len(set(s.goal_types)) != len(s.goal_types) for s in self.subtasks)
-
-    @property
-    def goal_index(self):
-        """Per subtask, the index of its goal object among the level's distinct goal objects
-        (order of first appearance) -- how dup-mode state words store goal_objects_count."""
-        seen, out = [], []
-        for s in self.subtasks:
-            if s.goal_sig not in seen:
-                seen.append(s.goal_sig)
-            out.append(seen.index(s.goal_sig))
-        return out
 
     @property
     def hip_supported(self):

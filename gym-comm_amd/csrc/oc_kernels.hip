@@ -86,6 +86,14 @@ struct RunCfg {
   uint32_t allergic;  // bit a: agent a is ALLERGIC
   double inv_T;       // 1.0 / T, correctly rounded on the host (0 when T == 0)
   double inv_max_path;  // 1.0 / MAX_PATH, correctly rounded on the host
+  // The caller's subtask order is run-time data too.  Inside the kernels subtask bits sit in a
+  // CANONICAL order (Chop / Merge subtasks sorted by kind, goal object and food; Deliver subtasks
+  // after them in the caller's order, which the fp64 shaping sum follows), so one specialised
+  // library serves every order of a level -- the reference's own order is `set` iteration order
+  // and changes with PYTHONHASHSEED (recipe_planner/stripsworld.py:72-77).  slot4: byte s = the
+  // bit of the caller's subtask s; only the completed_subtasks observation rows need it.
+  uint32_t slot_identity;
+  uint32_t slot4[OC_MAX_SUBTASKS / 4];
 };
 
 #ifdef OC_STAMPS
@@ -166,6 +174,8 @@ using Hdr = HdrK;
 struct oc_level {
   LevelHdr hdr;
   RunCfg run;
+  int32_t slot[OC_MAX_SUBTASKS];        // canonical bit of the caller's subtask s
+  int32_t goal_index[OC_MAX_SUBTASKS];  // index of its distinct goal object (dup mode: where its count lives)
   void *dev_tables;    // [nquot] fp64 quotients k / max_path, then [ncells*ncells] u8 distances
   int32_t n16;         // table bytes / 16 (rounded up)
   int32_t quot_bytes;
@@ -955,7 +965,7 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
 // OT = element type of the observation rows: 0 int32, 1 int8, 2 float32 (the same integers,
 // converted; what a policy network's first layer consumes as obs[v].T without a cast)
 template <int A, int M, bool DUP, int OT, typename OutRows>
-__device__ __forceinline__ void env_obs(const Hdr &L, const Env<A, M, DUP> &e, int viewer, int radius,
+__device__ __forceinline__ void env_obs(const Hdr &L, const RunCfg &R, const Env<A, M, DUP> &e, int viewer, int radius,
                                         bool viewer_blind, bool ego_blind, int C, int comm0, int comm1,
                                         const OutRows &out, int row0) {
   const int vp = viewer == 0 ? e.ap[0] : e.ap[1];
@@ -1004,7 +1014,11 @@ __device__ __forceinline__ void env_obs(const Hdr &L, const Env<A, M, DUP> &e, i
   for (int ch = 0; ch < 4; ch++) OUT(row++, st[ch]);
 #pragma unroll
   for (int ch = 0; ch < 4; ch++) OUT(row++, hid[ch]);
-  for (int s = 0; s < L.S(); s++) OUT(row++, (e.completed >> s) & 1);
+  if (R.slot_identity) {   // uniform: the caller's order is the canonical one
+    for (int s = 0; s < L.S(); s++) OUT(row++, (e.completed >> s) & 1);
+  } else {
+    for (int s = 0; s < L.S(); s++) OUT(row++, (e.completed >> ((R.slot4[s >> 2] >> (8 * (s & 3))) & 31)) & 1);
+  }
 #pragma unroll
   for (int k = 0; k < 4; k++) OUT(row++, loc[k]);
   OUT(row++, ego_blind ? 0 : (vhp != 0 ? 1 : 0));  // :154, gated on the EGO's BLIND flag
@@ -1303,7 +1317,7 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
   const Out ob(p.obs, p.n, 2 * F, i, OT == 1 ? 1 : 4);
 #pragma unroll
   for (int v = 0; v < 2; v++)
-    env_obs<A, M, DUP, OT>(L, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
+    env_obs<A, M, DUP, OT>(L, p.R, e, v, p.cfg.fow_radius, (p.cfg.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob, v * F);
   Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));  // overcooked_env.py:146
 }
 
@@ -1589,7 +1603,7 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     const Out ob(p.obs, p.n, 2 * F, i, OT == 1 ? 1 : 4);
 #pragma unroll
     for (int v = 0; v < 2; v++)
-      env_obs<A, M, DUP, OT>(L, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
+      env_obs<A, M, DUP, OT>(L, p.R, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
                         v * F);
     Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
     OC_STAMP(5);   // observation stores issued
@@ -1745,7 +1759,8 @@ uint32_t probe_code(int x, int y) {
 
 // Level blob (include/oc_level.h) -> LevelHdr + RunCfg.  Host only, no device work.
 // Returns NULL on success, else a message.
-const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg &run) {
+const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg &run,
+                         int32_t *slot_out = nullptr, int32_t *goal_index_out = nullptr) {
   if (!b || n_words < OC_LV_HEADER_WORDS) return "null or short blob";
   if (b[OC_LV_MAGIC] != OC_LV_MAGIC_VALUE || b[OC_LV_VERSION] != OC_LV_VERSION_VALUE ||
       b[OC_LV_TOTAL] != n_words)
@@ -1804,8 +1819,38 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
               h.name_sig[h.nnames++] = (uint32_t)(a | (b2 << 2) | (c << 4) | (d << 6));
             }
   }
-  for (int s = 0; s < S; s++) {
-    const int kind = st[4 * s], sig = st[4 * s + 1], food = st[4 * s + 2];
+  // canonical subtask slots (see RunCfg): Chop / Merge subtasks sorted by (kind, goal object,
+  // food), ties in the caller's order -- tied subtasks are indistinguishable to the kernels --
+  // then the Deliver subtasks in the caller's order
+  int order[OC_MAX_SUBTASKS], slot[OC_MAX_SUBTASKS], nord = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (int u = 0; u < S; u++)
+      if ((st[4 * u] == OC_DELIVER) == (pass == 1)) order[nord++] = u;
+  for (int i = 1; i < S; i++) {   // insertion sort of the non-Deliver prefix (stable)
+    const int u = order[i];
+    if (st[4 * u] == OC_DELIVER) break;
+    int j = i;
+    while (j > 0) {
+      const int v = order[j - 1];
+      const bool greater = st[4 * v] != st[4 * u] ? st[4 * v] > st[4 * u]
+                           : st[4 * v + 1] != st[4 * u + 1] ? st[4 * v + 1] > st[4 * u + 1]
+                                                            : st[4 * v + 2] > st[4 * u + 2];
+      if (!greater) break;
+      order[j] = v;
+      j--;
+    }
+    order[j] = u;
+  }
+  run.slot_identity = 1;
+  memset(run.slot4, 0, sizeof(run.slot4));
+  for (int c = 0; c < S; c++) {
+    slot[order[c]] = c;
+    if (order[c] != c) run.slot_identity = 0;
+  }
+  for (int u = 0; u < S; u++) run.slot4[u >> 2] |= (uint32_t)slot[u] << (8 * (u & 3));
+  for (int s = 0; s < S; s++) {   // s = canonical slot from here on
+    const int u = order[s];
+    const int kind = st[4 * u], sig = st[4 * u + 1], food = st[4 * u + 2];
     const int s7 = sig7_of_sig(sig);
     if (s7 < 0) return "goal object holds more than three of a food or two Plates";
     // goals are told apart by their multiset in dup mode, by their type set otherwise (the same
@@ -1834,6 +1879,8 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
       h.goal_tset[h.ngoal++] = (uint32_t)ts;
     }
     if (kind == OC_DELIVER) h.goal_dl[g] |= 1u << s; else h.goal_nd[g] |= 1u << s;
+    if (slot_out) slot_out[u] = s;
+    if (goal_index_out) goal_index_out[u] = (int32_t)g;
   }
   // pair term: Plate + recipe[0] ingredient names, every unordered pair in that order
   // (overcooked_environment.py:319-363); one distance lookup per item pair
@@ -1953,7 +2000,7 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   if (!lv) return fail(OC_E_BADARG, "oc_level_create: out of memory");
   lv->dev_tables = nullptr;
   LevelHdr &h = lv->hdr;
-  const char *msg = build_header(b, n_words, h, lv->run);
+  const char *msg = build_header(b, n_words, h, lv->run, lv->slot, lv->goal_index);
   if (msg) {
     delete lv;
     snprintf(g_err, sizeof(g_err), "oc_level_create: %s", msg);
@@ -2023,6 +2070,23 @@ int oc_level_destroy(oc_level_t *lv) {
   if (!lv) return OC_OK;
   if (lv->dev_tables) (void)hipFree(lv->dev_tables);
   delete lv;
+  return OC_OK;
+}
+
+int oc_level_subtask_info(const int32_t *b, int32_t n_words, int32_t *slot, int32_t *goal_index, int32_t *dup) {
+  LevelHdr h;
+  RunCfg run;
+  int32_t sl[OC_MAX_SUBTASKS], gi[OC_MAX_SUBTASKS];
+  const char *msg = build_header(b, n_words, h, run, sl, gi);
+  if (msg) {
+    snprintf(g_err, sizeof(g_err), "oc_level_subtask_info: %s", msg);
+    return OC_E_BADARG;
+  }
+  for (int s = 0; s < h.S; s++) {
+    if (slot) slot[s] = sl[s];
+    if (goal_index) goal_index[s] = gi[s];
+  }
+  if (dup) *dup = (int32_t)h.has_dup;
   return OC_OK;
 }
 

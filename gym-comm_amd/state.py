@@ -2,13 +2,14 @@
 import numpy as np
 
 
-def unpack_state(words, A, M, S, goal_index=None, deliver=None):
+def unpack_state(words, A, M, S, slot=None, goal_index=None, deliver=None):
     """words: int array [A+M+2, n] (numpy).  Returns the canonical snapshot used by the
     golden fixtures and the oracle:
       items  [n][M][5]  x, y, state_index, group, holder agent (-1)
       order  [n][M]     groups in world.objects iteration order, -1 padded
       agents [n][A][3]  x, y, held group (-1)
       t, completed [n][S], goal_count [n][S], merge_counter, error
+    slot (per subtask: its bit in the state's subtask words; BatchedOvercooked.unpack_kw()).
     goal_index / deliver (per subtask: index of its distinct goal object, is-a-Deliver flag):
     given for a level in dup mode, where the state keeps 2-bit counts per distinct goal; the
     seq field of such a level is kseq<<4 | seq, still a world-order sort key.
@@ -27,7 +28,9 @@ def unpack_state(words, A, M, S, goal_index=None, deliver=None):
     idx = np.argsort(key, axis=1, kind="stable")
     order = np.where(np.take_along_axis(is_rep, idx, axis=1), idx, -1)
     m0, m1 = w[A + M] & 0xFFFFFFFF, w[A + M + 1] & 0xFFFFFFFF
-    bits = np.arange(S)
+    # the kernels keep subtask bits in a canonical order of their own (include/oc_hip.h,
+    # oc_level_subtask_info): slot[s] = the bit of the caller's subtask s (default: bit s)
+    bits = np.arange(S) if slot is None else np.asarray(slot)
     if goal_index is None:
         goal_count = (m1[:, None] >> bits) & 1
     else:

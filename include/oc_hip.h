@@ -52,8 +52,11 @@ typedef struct oc_level oc_level_t; /* opaque; device-resident static tables */
  *                                      order (initial items 0..M-1, the k-th merge of
  *                                      the episode gets M+k)
  *                             tset   = set of content types of the Object (bit t = type t)
- *   row A+M         completed_subtasks bitmask (bit s = subtask s)
- *   row A+M+1       goal_objects_count bits (bit s = the goal object of subtask s exists)
+ *   row A+M         completed_subtasks bitmask (bit oc_level_subtask_info().slot[s] = subtask s)
+ *   row A+M+1       goal_objects_count: one bit per subtask (same slots; the goal object of the
+ *                   subtask exists), or -- a level that repeats a content type -- two bits per
+ *                   distinct goal object (goal_index[s]), the number of cells holding one
+ *   rows A+M+2, +3  only in such a "dup" level: creation ranks of the merged object names
  * Replaces the World / SimAgent object graph (gym_cooking/utils/world.py:14-320,
  * utils/agent.py:258-314, utils/core.py:149-237). */
 
@@ -145,6 +148,16 @@ OC_API int oc_level_destroy(oc_level_t *lv);
  *   length, or a negative OC_E_* code.  Host only -- needs no GPU. */
 OC_API int oc_level_spec_source(const int32_t *blob, int32_t n_words, char *buf, int32_t buf_size);
 OC_API int oc_is_specialized(void);
+/* Where the state tensor keeps a subtask's bits.  The kernels order subtasks canonically
+ * (Chop / Merge sorted by kind, goal object and food, then the Deliver subtasks in the blob's
+ * order), so that one specialised library serves every subtask order of a level -- the
+ * reference's order changes with PYTHONHASHSEED (recipe_planner/stripsworld.py:72-77).  For the
+ * blob's subtask s: slot[s] = its bit in the completed_subtasks / goal_objects_count words;
+ * goal_index[s] = the index of its distinct goal object (a level in dup mode stores
+ * goal_objects_count as two bits per distinct goal); *dup = the level repeats a content type.
+ * The completed_subtasks observation rows are already in the blob's order.  Host only. */
+OC_API int oc_level_subtask_info(const int32_t *blob, int32_t n_words, int32_t *slot, int32_t *goal_index,
+                                 int32_t *dup);
 OC_API int64_t oc_metrics_slots(int64_t n);                         /* ceil(n / 64) */
 OC_API int32_t oc_state_words(const oc_level_t *lv);                 /* A + M + 2 */
 OC_API int32_t oc_obs_rows(const oc_level_t *lv, int32_t num_comm);  /* 22 + S + 2C */

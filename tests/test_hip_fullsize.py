@@ -70,7 +70,7 @@ def test_full_size_tiles_of_oracle_checked_batch(level, A, n, wrapper, oracle_li
             rsum += int(r[:N0].sum().item())
         assert _tiled_equal(env.state, N0), ctx
         if k % 10 == 9 or k == steps - 1:
-            hs = unpack_state(env.state[:, :N0].cpu().numpy(), lv.num_agents, lv.num_items, lv.num_subtasks)
+            hs = unpack_state(env.state[:, :N0].cpu().numpy(), lv.num_agents, lv.num_items, lv.num_subtasks, **env.unpack_kw())
             os_ = ora.snapshot_all()
             assert_snapshots_equal(hs, os_, ctx, where=(os_["error"] == 0) & (hs["error"] == 0))
     m = env.read_metrics()
