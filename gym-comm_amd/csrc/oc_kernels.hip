@@ -1457,8 +1457,11 @@ struct MultiArgs {
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
-// XO = false: the plain step (actions from the four rows, no episode statistics): `p.opt` is not
-// even looked at, so the optional features cost the headline path nothing.
+// XO = false: the plain step in the wrapper's standard configuration -- actions from the four
+// rows, no episode statistics (`p.opt` is not even looked at), communication on, not ego-led,
+// both players CAN_MOVE, ego = sim agent 0, nobody BLIND (the reference's env_args*.json and
+// BASELINE.md section 3) -- with those settings folded: no selects on them, no BLIND branch and
+// none of the register copies its join costs.  Anything else runs the general variant (XO = true).
 template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO>
 __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
                                                     int32_t *const comm_, int64_t *const metrics_,
@@ -1559,8 +1562,11 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     OC_STAMP(1);   // state + actions arrived
     // comm one-hots (:227-246); an index the reference's one_hot[idx] = 1 would raise on is
     // flagged (OC_ERR_ACTION) and sends nothing
+    const bool cfg_comm_on = XO ? p.cfg.communication_on != 0 : true, cfg_ego_led = XO ? p.cfg.ego_led != 0 : false;
+    const int cfg_can_move = XO ? p.cfg.can_move_mask : 3, cfg_ego_idx = XO ? p.cfg.ego_agent_idx : 0;
+    const int cfg_blind = XO ? p.cfg.obs.blind_mask : 0;
     const unsigned NC = (unsigned)p.cfg.obs.num_comm;
-    const bool ego_talks = p.cfg.communication_on, alt_talks = p.cfg.communication_on && !p.cfg.ego_led;
+    const bool ego_talks = cfg_comm_on, alt_talks = cfg_comm_on && !cfg_ego_led;
     const bool bad_cm = (ego_talks && (unsigned)ego_cm >= NC) | (alt_talks && (unsigned)alt_cm >= NC);
     const int c0 = (ego_talks && (unsigned)ego_cm < NC) ? ego_cm : -1;
     const int c1 = (alt_talks && (unsigned)alt_cm < NC) ? alt_cm : -1;
@@ -1569,11 +1575,11 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     // NAV_ACTIONS lookup (both indices, moved or not: :248) + CAN_MOVE gating + ego_agent_idx
     // (:250-262); NAV_ACTIONS[idx] raises for idx > 3: flagged, executed as (0, 0)
     const bool bad_mv = ((unsigned)ego_mv > 3u) | ((unsigned)alt_mv > 3u);
-    const int em = ((p.cfg.can_move_mask & 1) && (unsigned)ego_mv <= 3u) ? ego_mv : OC_ACT_NOOP;
-    const int am = ((p.cfg.can_move_mask & 2) && (unsigned)alt_mv <= 3u) ? alt_mv : OC_ACT_NOOP;
+    const int em = ((cfg_can_move & 1) && (unsigned)ego_mv <= 3u) ? ego_mv : OC_ACT_NOOP;
+    const int am = ((cfg_can_move & 2) && (unsigned)alt_mv <= 3u) ? alt_mv : OC_ACT_NOOP;
     int act[A];
-    act[0] = p.cfg.ego_agent_idx == 0 ? em : am;
-    act[1] = p.cfg.ego_agent_idx == 0 ? am : em;
+    act[0] = cfg_ego_idx == 0 ? em : am;
+    act[1] = cfg_ego_idx == 0 ? am : em;
     const int err_before = e.err;
     e.err |= (bad_mv | bad_cm) ? OC_ERR_ACTION : 0;
     ShapeIn<2> sin;
@@ -1599,11 +1605,11 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     shaping_lookup<2>(L, p.R.inv_max_path, sin, sld, sq OC_STAMP_PASS);
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S() + 2 * C;
-    const bool ego_blind = p.cfg.obs.blind_mask & 1;
+    const bool ego_blind = cfg_blind & 1;
     const Out ob(p.obs, p.n, 2 * F, i, OT == 1 ? 1 : 4);
 #pragma unroll
     for (int v = 0; v < 2; v++)
-      env_obs<A, M, DUP, OT>(L, p.R, e, v, p.cfg.obs.fow_radius, (p.cfg.obs.blind_mask >> v) & 1, ego_blind, C, c0, c1, ob,
+      env_obs<A, M, DUP, OT>(L, p.R, e, v, p.cfg.obs.fow_radius, (cfg_blind >> v) & 1, ego_blind, C, c0, c1, ob,
                         v * F);
     Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
     OC_STAMP(5);   // observation stores issued
@@ -2218,7 +2224,9 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   const int ot = cfg->obs.obs_int8;   // 0 int32, 1 int8, 2 float32
   if (ot < 0 || ot > 2) return fail(OC_E_BADARG, "oc_multi_step: obs_int8 must be 0 (int32), 1 (int8) or 2 (float32)");
   const bool wt = write_through(n);
-  const bool xo = o.ep_return || o.ego_pairs || o.alt_pairs || o.alt_rng;
+  const bool std_cfg = cfg->communication_on && !cfg->ego_led && cfg->can_move_mask == 3 &&
+                       cfg->ego_agent_idx == 0 && cfg->obs.blind_mask == 0;
+  const bool xo = o.ep_return || o.ego_pairs || o.alt_pairs || o.alt_rng || !std_cfg;
 #define OC_MS_X(MM, DD, XX)                                                           \
   do {                                                                                \
     if (in_lds && ot == 0) return launch_ms(k_multi_step<MM, true, 0, false, DD, XX>, a, n, stream, lds);  \

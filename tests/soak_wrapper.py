@@ -28,6 +28,10 @@ def run(name, cfg, n, steps, seed, spec):
     rng = np.random.default_rng(seed)
     lv = compiler.compile_level(name, 2, cfg["T"], ego_allergic=cfg["ego"]["ALLERGIC"],
                                 partner_allergic=cfg["partner"]["ALLERGIC"])
+    if cfg["shuffle"]:      # a random subtask order, as another PYTHONHASHSEED would give the reference
+        perm = [int(v) for v in rng.permutation(lv.num_subtasks)]
+        lv = compiler.compile_level(name, 2, cfg["T"], ego_allergic=cfg["ego"]["ALLERGIC"],
+                                    partner_allergic=cfg["partner"]["ALLERGIC"], subtask_order=perm)
     C = cfg["C"]
     kw = {}
     ora = oracle.OracleBatch(lv.blob, n, threads=16)
@@ -45,7 +49,7 @@ def run(name, cfg, n, steps, seed, spec):
                             ego_config=cfg["ego"], partner_config=cfg["partner"], num_communication=C,
                             communication_on=cfg["comm_on"], ego_led=cfg["ego_led"],
                             fow_radius=cfg["radius"], ego_agent_idx=cfg["ego_idx"],
-                            obs_dtype=cfg["odt"], **kw)
+                            obs_dtype=cfg["odt"], episode_stats=cfg["src"] != 0, **kw)
     if lv.random_placement:
         env.set_placement(torch.from_numpy(place).cuda())
         env.reset()
@@ -61,7 +65,13 @@ def run(name, cfg, n, steps, seed, spec):
         if k % 3:
             a[0], a[2] = prev[0], prev[2]
         prev = a
-        o, t, r, d = env.multi_step(torch.from_numpy(a).cuda())
+        if cfg["src"] == 0:         # the four action rows
+            o, t, r, d = env.multi_step(torch.from_numpy(a).cuda())
+        else:                       # [n][2] pairs, int32 or int64 (oc_step_opts)
+            dt = torch.int32 if cfg["src"] == 1 else torch.int64
+            ego = torch.from_numpy(np.ascontiguousarray(a[0:2].T)).cuda().to(dt)
+            alt = torch.from_numpy(np.ascontiguousarray(a[2:4].T)).cuda().to(dt)
+            o, t, r, d = env.multi_step(None, ego_pairs=ego, alt_pairs=alt)
         oo, to, ro, do = ora.multi_step(a, comm, cfg["radius"], blind, C, communication_on=cfg["comm_on"],
                                         ego_led=cfg["ego_led"], ego_agent_idx=cfg["ego_idx"],
                                         can_move_mask=can, auto_reset=True)
@@ -90,7 +100,7 @@ def main():
         flag = lambda p: bool(crng.random() < p)
         cfg = {"T": int(crng.choice([40, 100, 250])), "C": int(crng.choice([2, 2, 3, 5, 10])),
                "radius": int(crng.choice([0, 1, 2, 2, 3, 1000])), "comm_on": flag(0.8), "ego_led": flag(0.3),
-               "ego_idx": int(crng.choice([0, 0, 1])),
+               "ego_idx": int(crng.choice([0, 0, 1])), "shuffle": flag(0.6), "src": int(crng.integers(0, 3)),
                "odt": [torch.int32, torch.int32, torch.int8, torch.float32][int(crng.integers(0, 4))],
                "ego": {"ALLERGIC": flag(0.15), "BLIND": flag(0.15), "CAN_MOVE": not flag(0.1)},
                "partner": {"ALLERGIC": flag(0.15), "BLIND": flag(0.15), "CAN_MOVE": not flag(0.1)}}
