@@ -78,6 +78,9 @@ struct LevelHdr {
   uint32_t food_items[3];        // per food type: bit i = item i is of that type
   uint32_t nnames;               // merged names (multisets with >= 2 contents) a merge can create
   uint32_t name_sig[MAX_NAMES];
+  // two facts about the MAP that select code paths at compile time in a specialised build
+  uint32_t closed_border;        // every border cell is a non-Floor tile (see OC_BORDER_CLOSED)
+  uint32_t planes128;            // more than 64 cells: the tile bit-planes need both 64-bit words
 };
 
 // per-run settings that do not select a specialisation
@@ -117,50 +120,64 @@ struct RunCfg {
 #endif
 
 // The kernels read the level through ACCESSORS (L.W(), L.goal_tset(g), ...), one list of fields
-// (OC_HDR_FIELDS) for two header classes:
-//   HdrC  specialised build: every accessor returns a field of the constexpr OC_SPEC_HDR, so loop
-//         bounds, type tests and bit-planes fold at compile time;
-//   HdrK  generic build: the struct travels by value in the kernel arguments and an accessor is a
-//         scalar load from the kernarg segment (uniform, no VGPRs, no LDS, no barrier).
+// (OC_HDR_FIELDS) for two header classes.  The fields come in two kinds:
+//   STRUCTURE  what the recipes and the item multiset fix -- subtask masks, goal objects, item
+//              types, the shaping lookup programs, the two map flags above;
+//   GEOMETRY   the map itself -- size, tile bit-planes, Delivery positions, start cells (the
+//              distance and Counter tables are device buffers anyway).
+//   HdrC  specialised build: STRUCTURE accessors return fields of the constexpr OC_SPEC_HDR, so
+//         loop bounds, type tests and masks fold at compile time; GEOMETRY accessors read the
+//         by-value kernel argument (a dozen scalar loads).  A specialised library is therefore
+//         keyed by the STRUCTURE alone: every map with the same recipes, item multiset, agent
+//         count and border kind runs on it -- all `*_tomato` levels share one library, and so
+//         does a user-made map with those recipes on a box that has no hipcc.
+//   HdrK  generic build: both kinds are scalar loads from the kernel arguments.
 // (Tried and dropped in round 2: the header spread over the lanes of three VGPRs, one
 // v_readlane per access.  Slower -- 7.68 us per step at 4 096 envs against 6.97 us with kernarg
 // loads: ~290 readlanes with their SGPR-hazard wait states cost more than the scalar-cache hits
 // they replace -- and unsafe: the compiler may copy such a VGPR under a partial EXEC mask, which
 // loses the words parked in inactive lanes.)
-#define OC_HDR_FIELDS(FLD, ARR, ARR64)                                                                     \
-  FLD(int32_t, W) FLD(int32_t, H) FLD(int32_t, ncells) FLD(int32_t, max_path) FLD(int32_t, S)                \
-  FLD(int32_t, A) FLD(int32_t, M) FLD(uint32_t, item_types)                                              \
-  ARR64(nonfloor) ARR64(cell_lo) ARR64(cell_hi)                                                          \
-  FLD(uint32_t, nondeliver_mask) FLD(uint32_t, deliver_mask)                                           \
-  ARR(uint32_t, chop_mask) ARR(uint32_t, food_item)                                                    \
-  FLD(uint32_t, ngoal) ARR(uint32_t, goal_tset) ARR(uint32_t, goal_nd) ARR(uint32_t, goal_dl)             \
-  FLD(uint32_t, ndel) ARR(uint32_t, del_tset) ARR(uint32_t, del_bit)                                     \
-  FLD(uint32_t, npairlk) ARR(uint32_t, pairlk) FLD(uint32_t, pair_static_max)                            \
-  FLD(uint32_t, ndeliv) ARR(uint32_t, deliv_pos) ARR(int32_t, init_words) FLD(uint32_t, nquot)            \
-  FLD(uint32_t, nscatter) FLD(uint32_t, ncounters) ARR(uint32_t, scatter_item)                           \
-  FLD(uint32_t, has_dup) ARR(uint32_t, goal_sig) ARR(uint32_t, del_sig) ARR(uint32_t, food_items)         \
-  FLD(uint32_t, nnames) ARR(uint32_t, name_sig)
+#define OC_HDR_FIELDS(FLD, ARR, ARR64, GFLD, GARR, GARR64)                                           \
+  GFLD(int32_t, W) GFLD(int32_t, H) GFLD(int32_t, ncells) GFLD(int32_t, max_path) FLD(int32_t, S)  \
+  FLD(int32_t, A) FLD(int32_t, M) FLD(uint32_t, item_types)                                        \
+  GARR64(nonfloor) GARR64(cell_lo) GARR64(cell_hi)                                                 \
+  FLD(uint32_t, nondeliver_mask) FLD(uint32_t, deliver_mask)                                       \
+  ARR(uint32_t, chop_mask) ARR(uint32_t, food_item)                                                \
+  FLD(uint32_t, ngoal) ARR(uint32_t, goal_tset) ARR(uint32_t, goal_nd) ARR(uint32_t, goal_dl)     \
+  FLD(uint32_t, ndel) ARR(uint32_t, del_tset) ARR(uint32_t, del_bit)                               \
+  FLD(uint32_t, npairlk) ARR(uint32_t, pairlk) FLD(uint32_t, pair_static_max)                      \
+  FLD(uint32_t, ndeliv) GARR(uint32_t, deliv_pos) GARR(int32_t, init_words) GFLD(uint32_t, nquot) \
+  FLD(uint32_t, nscatter) GFLD(uint32_t, ncounters) ARR(uint32_t, scatter_item)                    \
+  FLD(uint32_t, has_dup) ARR(uint32_t, goal_sig) ARR(uint32_t, del_sig) ARR(uint32_t, food_items) \
+  FLD(uint32_t, nnames) ARR(uint32_t, name_sig) FLD(uint32_t, closed_border) FLD(uint32_t, planes128)
 
 #ifdef OC_SPECIALIZED
 #include OC_SPEC_FILE  // constexpr LevelHdr OC_SPEC_HDR = {...};
 struct HdrC {
+  const LevelHdr &k;   // the by-value kernel argument: the map's geometry
 #define OC_F(T, name) __device__ __forceinline__ constexpr T name() const { return OC_SPEC_HDR.name; }
 #define OC_A(T, name) __device__ __forceinline__ constexpr T name(int i) const { return OC_SPEC_HDR.name[i]; }
 #define OC_A64(name) __device__ __forceinline__ constexpr uint64_t name(int i) const { return OC_SPEC_HDR.name[i]; }
-  OC_HDR_FIELDS(OC_F, OC_A, OC_A64)
+#define OC_GF(T, name) __device__ __forceinline__ T name() const { return k.name; }
+#define OC_GA(T, name) __device__ __forceinline__ T name(int i) const { return k.name[i]; }
+#define OC_GA64(name) __device__ __forceinline__ uint64_t name(int i) const { return k.name[i]; }
+  OC_HDR_FIELDS(OC_F, OC_A, OC_A64, OC_GF, OC_GA, OC_GA64)
 #undef OC_F
 #undef OC_A
 #undef OC_A64
+#undef OC_GF
+#undef OC_GA
+#undef OC_GA64
 };
 using Hdr = HdrC;
-#define OC_HDR_LOAD(args) const HdrC L {}
+#define OC_HDR_LOAD(args) const HdrC L {(args).L}
 #else
 struct HdrK {
   const LevelHdr &k;   // the by-value kernel argument
 #define OC_F(T, name) __device__ __forceinline__ T name() const { return k.name; }
 #define OC_A(T, name) __device__ __forceinline__ T name(int i) const { return k.name[i]; }
 #define OC_A64(name) __device__ __forceinline__ uint64_t name(int i) const { return k.name[i]; }
-  OC_HDR_FIELDS(OC_F, OC_A, OC_A64)
+  OC_HDR_FIELDS(OC_F, OC_A, OC_A64, OC_F, OC_A, OC_A64)
 #undef OC_F
 #undef OC_A
 #undef OC_A64
@@ -292,7 +309,7 @@ __device__ __forceinline__ int bit128(uint64_t w0, uint64_t w1, int c) {
 __device__ __forceinline__ int item_type(const Hdr &L, int i) { return (L.item_types() >> (4 * i)) & 15; }
 // tile type (OC_FLOOR / COUNTER / CUTBOARD / DELIVERY) of dense cell c
 __device__ __forceinline__ int cell_type(const Hdr &L, int c) {
-  if (L.ncells() <= 64)  // uniform (compile-time in specialised builds): one 64-bit plane each
+  if (!L.planes128())  // uniform (compile-time in specialised builds): one 64-bit plane each
     return (int)((L.cell_lo(0) >> c) & 1) | ((int)((L.cell_hi(0) >> c) & 1) << 1);
   return bit128(L.cell_lo(0), L.cell_lo(1), c) | (bit128(L.cell_hi(0), L.cell_hi(1), c) << 1);
 }
@@ -311,7 +328,7 @@ constexpr bool border_closed(const LevelHdr &L) {
   return true;
 }
 #ifdef OC_SPECIALIZED
-constexpr bool OC_BORDER_CLOSED = border_closed(OC_SPEC_HDR);
+constexpr bool OC_BORDER_CLOSED = OC_SPEC_HDR.closed_border != 0;   // (set by build_header from the map)
 #else
 constexpr bool OC_BORDER_CLOSED = false;
 #endif
@@ -1922,6 +1939,8 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
     if (n_groups * h.max_path > kmax) kmax = n_groups * h.max_path;      // pair term numerator
     h.nquot = (uint32_t)(kmax + 2);
   }
+  h.closed_border = border_closed(h) ? 1u : 0u;
+  h.planes128 = nc > 64 ? 1u : 0u;
   h.nscatter = (uint32_t)b[OC_LV_NSCATTER];
   h.ncounters = (uint32_t)b[OC_LV_NCOUNTERS];
   if (h.nscatter > 4 || h.ncounters > OC_MAX_COUNTERS || (h.nscatter > 0 && h.ncounters < h.nscatter))
@@ -1932,6 +1951,21 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
     h.scatter_item[k] = (uint32_t)item;
   }
   return nullptr;
+}
+
+// The STRUCTURE of a level (see OC_HDR_FIELDS): the header with the map's geometry blanked.  A
+// specialised library is generated from, and checks new levels against, this part only.
+LevelHdr structure_of(const LevelHdr &h) {
+  LevelHdr t = h;
+  t.W = t.H = t.ncells = t.max_path = 0;
+  memset(t.nonfloor, 0, sizeof(t.nonfloor));
+  memset(t.cell_lo, 0, sizeof(t.cell_lo));
+  memset(t.cell_hi, 0, sizeof(t.cell_hi));
+  memset(t.deliv_pos, 0, sizeof(t.deliv_pos));
+  memset(t.init_words, 0, sizeof(t.init_words));
+  t.nquot = 0;
+  t.ncounters = 0;
+  return t;
 }
 
 }  // namespace
@@ -1950,13 +1984,14 @@ int oc_is_specialized(void) {
 }
 
 int oc_level_spec_source(const int32_t *b, int32_t n_words, char *buf, int32_t buf_size) {
-  LevelHdr h;
+  LevelHdr full, h;
   RunCfg run;
-  const char *msg = build_header(b, n_words, h, run);
+  const char *msg = build_header(b, n_words, full, run);
   if (msg) {
     snprintf(g_err, sizeof(g_err), "oc_level_spec_source: %s", msg);
     return OC_E_BADARG;
   }
+  h = structure_of(full);   // the geometry stays a run-time argument of the specialised kernels
   if (!buf || buf_size < 64) return fail(OC_E_BADARG, "oc_level_spec_source: buffer too small");
   // LevelHdr holds 32-bit words and three pairs of 64-bit planes; emit it field by field
   // in declaration order as one aggregate initialiser.
@@ -1993,6 +2028,7 @@ int oc_level_spec_source(const int32_t *b, int32_t n_words, char *buf, int32_t b
   EMIT_ARR(h.food_items, 3);
   EMIT("  %uu,\n", h.nnames);
   EMIT_ARR(h.name_sig, MAX_NAMES);
+  EMIT("  %uu, %uu\n", h.closed_border, h.planes128);
   EMIT("};\n");
 #undef EMIT_ARR
 #undef EMIT
@@ -2014,10 +2050,11 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   }
 #ifdef OC_SPECIALIZED
   {
-    const LevelHdr spec = OC_SPEC_HDR;
-    if (memcmp(&spec, &h, sizeof(LevelHdr)) != 0) {
+    const LevelHdr spec = OC_SPEC_HDR, mine = structure_of(h);
+    if (memcmp(&spec, &mine, sizeof(LevelHdr)) != 0) {
       delete lv;
-      return fail(OC_E_BADARG, "oc_level_create: this library is specialised for a different level");
+      return fail(OC_E_BADARG, "oc_level_create: this library is specialised for a different level structure "
+                               "(recipes, item multiset, agent count, border kind)");
     }
   }
 #endif

@@ -727,6 +727,32 @@ OC_EXPORT void oc_oracle_step(void *h, const int32_t *actions, int32_t *reward, 
   *done = d;
 }
 
+/* TEST ONLY: put a freshly reset env into a hand-made state of single-content objects, so that
+ * corners random play practically never reaches (e.g. the World.remove alias, world.py:239-247)
+ * can be staged.  agents [A][3] = x, y, held item id (-1 = empty hands); items [M][3] = x, y,
+ * state_index (a held item sits on its holder's cell whatever x, y say). */
+OC_EXPORT void oc_oracle_debug_set(void *h, const int32_t *agents, const int32_t *items) {
+  Env *e = (Env *)h;
+  env_reset(e); /* object i = item i; keys by type in world order */
+  for (int i = 0; i < e->M; i++) {
+    e->objs[i].x = items[3 * i];
+    e->objs[i].y = items[3 * i + 1];
+    e->objs[i].is_held = 0;
+    e->items[i].state = items[3 * i + 2];
+  }
+  for (int a = 0; a < e->A; a++) {
+    e->ax[a] = agents[3 * a];
+    e->ay[a] = agents[3 * a + 1];
+    e->ahold[a] = agents[3 * a + 2];
+    if (e->ahold[a] >= 0) {
+      Obj *o = &e->objs[e->ahold[a]];
+      o->is_held = 1;
+      o->x = e->ax[a];
+      o->y = e->ay[a];
+    }
+  }
+}
+
 OC_EXPORT int oc_oracle_successful(const void *h) { return ((const Env *)h)->successful; }
 OC_EXPORT int oc_oracle_error(const void *h) { return ((const Env *)h)->err; }
 

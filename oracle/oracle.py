@@ -76,6 +76,7 @@ def lib():
         L.oc_oracle_batch_snapshot.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64] + [_I32P] * 7
         L.oc_oracle_batch_reset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, _I32P]
         L.oc_oracle_pyset_order.argtypes = [_I32P, ctypes.c_int, _I32P]
+        L.oc_oracle_debug_set.argtypes = [ctypes.c_void_p, _I32P, _I32P]
         _lib = L
     return _lib
 
@@ -162,6 +163,13 @@ class OracleEnv:
         else:
             a = np.ascontiguousarray(cells, dtype=np.int32)
             lib().oc_oracle_set_placement(self._h, _p32(a))
+
+    def debug_set(self, agents, items):
+        """TEST ONLY: stage a state of single-content objects (oc_oracle_debug_set): agents
+        [A][3] = x, y, held item (-1); items [M][3] = x, y, state_index."""
+        a = np.ascontiguousarray(agents, dtype=np.int32).reshape(self.A, 3)
+        it = np.ascontiguousarray(items, dtype=np.int32).reshape(self.M, 3)
+        lib().oc_oracle_debug_set(self._h, _p32(a), _p32(it))
 
     def step(self, actions):
         act = np.ascontiguousarray(actions, dtype=np.int32)

@@ -666,3 +666,96 @@ def test_action_sources_agree(oracle_lib):
     assert (err[::3] == 4).all() and (err[1::3] == 4).all() and (err[2::3] == 0).all()
     with pytest.raises(ValueError):
         e.multi_step(None, ego_pairs=big)           # no source for the partner
+
+
+def _stage(env, lv, agents, items):
+    """Put every env of the batch into a hand-made state of single-content objects: the twin of
+    OracleEnv.debug_set (agents [x, y, held item or -1], items [x, y, state_index])."""
+    env.reset()
+    w = env.state.cpu().numpy().copy()                 # [A+M+2][n] packed words (include/oc_hip.h)
+    A = lv.num_agents
+    for a, (x, y, h) in enumerate(agents):
+        w[a] = (w[a] & ~0xFFF) | x | (y << 4) | ((h + 1) << 8 if h >= 0 else 0)
+    for i, (x, y, st) in enumerate(items):
+        holder = [a for a, ag in enumerate(agents) if ag[2] == i]
+        if holder:
+            x, y = agents[holder[0]][0], agents[holder[0]][1]
+        w[A + i] = (w[A + i] & ~(0xFF | 0x100 | 0x7000)) | x | (y << 4) | (st << 8) | \
+                   (((holder[0] + 1) if holder else 0) << 12)
+    env.state.copy_(torch.from_numpy(w).cuda())
+
+
+@pytest.mark.parametrize("spec", [False, True], ids=["generic", "spec"])
+def test_world_remove_alias_corner_staged(spec, oracle_lib):
+    """The `World.remove` alias corner (utils/world.py:239-247) on a shipped 3-agent level, staged
+    because random play practically never reaches it: agents 0 and 2 stand on ONE cell, each
+    holding a Plate, and agent 0 merges its plate with the chopped Tomato on the counter next to
+    it.  remove() deletes by (name, location) and takes the LAST match: when agent 0 holds the
+    plate that comes first in world order it deletes agent 2's plate instead -- the reference's
+    store is corrupt from there on, kernel and oracle both flag OC_ERR_ALIAS; with the plates
+    swapped the merge is clean and the full states agree."""
+    from gym_comm_amd import compiler
+    lv = compiler.compile_level("open-divider_tl", 3, 100)
+    assert [t for t, _, _ in lv.items] == [0, 1, 3, 3]                 # Tomato, Lettuce, Plate, Plate
+    items = [[0, 4, 1], [6, 1, 0], [6, 5, 0], [5, 6, 0]]               # the Tomato chopped, on Counter (0, 4)
+    n = 130
+    acts = np.tile(np.array([[2], [4], [4]], np.int32), (1, n))         # agent 0 presses LEFT into the counter
+    for hold0, hold2, expect_err in ((2, 3, 2), (3, 2, 0)):
+        agents = [[1, 4, hold0], [3, 3, -1], [1, 4, hold2]]
+        env = _env(lv, n, auto_reset=False, specialize_level=spec)
+        _stage(env, lv, agents, items)
+        ora = oracle_lib.OracleBatch(lv.blob, n)
+        for i in range(n):
+            e = oracle_lib.OracleEnv.__new__(oracle_lib.OracleEnv)
+            e.A, e.M, e.S, e._h = ora.A, ora.M, ora.S, ora._handles[i]
+            try:
+                e.debug_set(agents, items)
+            finally:
+                e._h = None
+        assert_snapshots_equal(env.snapshot(), ora.snapshot_all(), "staged state")
+        r, d, sh = env.step(torch.from_numpy(acts).cuda())
+        ro, do, sho = ora.step(acts, auto_reset=False)
+        hs, os_ = env.snapshot(), ora.snapshot_all()
+        assert (hs["error"] == expect_err).all() and (os_["error"] == expect_err).all(), (hold0, hs["error"][:4])
+        assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(d.cpu().numpy(), do)
+        assert env.read_metrics()["errors"] == (n if expect_err else 0)
+        if not expect_err:
+            assert_snapshots_equal(hs, os_, "clean merge")
+            assert np.array_equal(bits(sh.cpu().numpy()), bits(sho))
+            assert (hs["nobj"] == 3).all() and (hs["agents"][:, 0, 2] == 0).all()   # agent 0 holds Plate-Tomato (group 0)
+
+
+def test_custom_map_runs_on_the_library_of_its_structure(oracle_lib):
+    """A map nobody pre-built, with the recipes / items / agent count / border kind of a shipped
+    level: it loads that structure's specialised library (geometry is a run-time argument) and
+    steps bit-exactly against the oracle -- base step and fused wrapper step."""
+    from gym_comm_amd import compiler, levels, specialize
+    text = "---t---\n/     -\n-  l  p\n*     -\n-     -\n--p----\n\nSalad\n\n1 1\n5 4"      # 7 x 6, our own
+    lv = compiler.compile_level(levels.parse_level_text("custom-7x6_salad", text), 2, 80)
+    assert specialize.spec_key(lv.blob) == specialize.spec_key(compiler.compile_level("open-divider_salad", 2, 80).blob)
+    n, steps, C = 900, 240, 3
+    rng = np.random.default_rng(5)
+    acts = scripted_then_random(rng, "custom", steps, 2, n)
+    env = _env(lv, n, auto_reset=True, specialize_level=True, num_communication=C, fow_radius=1)
+    assert env.kernel_flavour == "spec"
+    ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
+    tot = 0
+    for k in range(steps):
+        r, d, sh = env.step(torch.from_numpy(acts[k]).cuda())
+        ro, do, sho = ora.step(acts[k], auto_reset=True)
+        ctx = "custom map step %d" % k
+        assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(d.cpu().numpy(), do), ctx
+        assert np.array_equal(bits(sh.cpu().numpy()), bits(sho)), ctx
+        assert_snapshots_equal(env.snapshot(), ora.snapshot_all(), ctx)
+        tot += int(ro.sum())
+    assert tot > 0
+    env.reset(); ora.reset()
+    comm = np.zeros((2, n), np.int32)
+    mv = np.minimum(acts, 3)
+    cm = rng.integers(0, C, (steps, 2, n)).astype(np.int32)
+    for k in range(steps):
+        a = np.stack([mv[k, 0], cm[k, 0], mv[k, 1], cm[k, 1]]).astype(np.int32)
+        o, t, r, d = env.multi_step(torch.from_numpy(a).cuda())
+        oo, to, ro, do = ora.multi_step(a, comm, 1, 0, C, auto_reset=True)
+        assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(bits(r.cpu().numpy()), bits(ro)), k
+        assert np.array_equal(bits(t.cpu().numpy()), bits(to)) and np.array_equal(d.cpu().numpy(), do), k

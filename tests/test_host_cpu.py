@@ -343,7 +343,9 @@ def test_no_jit_compile_under_a_profiler(monkeypatch, tmp_path):
     inherit the profiler's preload: specialize.ensure() must not compile there (cached
     libraries still load), and the compiler children never see the profiler's variables."""
     from gym_comm_amd import compiler as C, specialize
-    txt = "-------\n/  t  l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSimpleTomato\n\n2 1\n4 1"
+    # a STRUCTURE nobody pre-built (a Tomato and three Plates); a new map of a known structure
+    # would simply load that structure's library
+    txt = "-------\n/  t  p\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSimpleTomato\n\n2 1\n4 1"
     (tmp_path / "uncached.txt").write_text(txt)
     lv = C.compile_level("uncached", 2, level_dir=str(tmp_path))
     assert not os.path.exists(specialize.spec_lib_path(lv.blob))
@@ -357,3 +359,28 @@ def test_no_jit_compile_under_a_profiler(monkeypatch, tmp_path):
     cached = C.compile_level("open-divider_tomato", 2, 500)          # built by __graft_entry__.build()
     if os.path.exists(specialize.spec_lib_path(cached.blob)):
         assert specialize.ensure(cached.blob) == specialize.spec_lib_path(cached.blob)
+
+
+def test_specialised_libraries_are_keyed_by_structure_not_by_map(tmp_path):
+    """A specialised library folds the STRUCTURE of a level (recipes, item multiset, agent count,
+    border kind); the map's geometry is a run-time argument.  So a user-made map with the recipes
+    and items of a shipped level loads that level's library -- no hipcc needed -- while another
+    recipe, agent count or border kind does not."""
+    import torch
+    from gym_comm_amd import _lib, compiler as C, specialize
+    key = lambda lv: specialize.spec_key(lv.blob)
+    base = C.compile_level("open-divider_tomato", 2, 100)
+    assert key(C.compile_level("full-divider_tomato", 2, 100)) == key(base)
+    assert key(C.compile_level("partial-divider_tomato", 2, 50)) == key(base)
+    mine = "---t---\n/     -\n-  l  p\n*     -\n-     -\n--p----\n\nSimpleTomato\n\n1 1\n5 4"   # 7 x 6, our own
+    (tmp_path / "mine.txt").write_text(mine)
+    lv = C.compile_level("mine", 2, 100, level_dir=str(tmp_path))
+    assert [t for t, _, _ in lv.items] == [t for t, _, _ in base.items] and lv.height == 6
+    assert key(lv) == key(base)
+    path = specialize.ensure(base.blob)
+    if path is not None:
+        rc, msg = _create(_lib.load(path), lv.blob)
+        assert rc == (0 if torch.cuda.is_available() else -2), msg
+    assert key(C.compile_level("open-divider_tomato", 3, 100)) != key(base)        # agent count
+    assert key(C.compile_level("open-divider_salad", 2, 100)) != key(base)         # recipes
+    assert key(C.compile_level("random-open-divider_tomato", 2, 100)) != key(base)  # items / open border
