@@ -66,7 +66,7 @@ def _declare(L):
     L.oc_last_error.restype = ctypes.c_char_p
     L.oc_level_create.argtypes = [_I32P, ctypes.c_int32, ctypes.POINTER(vp)]
     L.oc_level_destroy.argtypes = [vp]
-    L.oc_level_spec_source.argtypes = [_I32P, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
+    L.oc_level_spec_source.argtypes = [_I32P, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
     L.oc_level_subtask_info.argtypes = [_I32P, ctypes.c_int32, _I32P, _I32P, _I32P]
     L.oc_metrics_slots.argtypes = [ctypes.c_int64]
     L.oc_metrics_slots.restype = ctypes.c_int64

@@ -126,11 +126,15 @@ struct RunCfg {
 //   GEOMETRY   the map itself -- size, tile bit-planes, Delivery positions, start cells (the
 //              distance and Counter tables are device buffers anyway).
 //   HdrC  specialised build: STRUCTURE accessors return fields of the constexpr OC_SPEC_HDR, so
-//         loop bounds, type tests and masks fold at compile time; GEOMETRY accessors read the
-//         by-value kernel argument (a dozen scalar loads).  A specialised library is therefore
-//         keyed by the STRUCTURE alone: every map with the same recipes, item multiset, agent
-//         count and border kind runs on it -- all `*_tomato` levels share one library, and so
-//         does a user-made map with those recipes on a box that has no hipcc.
+//         loop bounds, type tests and masks fold at compile time.  GEOMETRY accessors come in
+//         two flavours of library:
+//           -DOC_SPEC_GEOMETRY  ("level" library) constexpr as well: everything folds, the
+//               fastest code (3.64 us per step, tomato-2 x 4096), valid for ONE map;
+//           otherwise           ("structure" library) they read the by-value kernel argument (a
+//               dozen scalar loads; 3.82 us): the library is keyed by the STRUCTURE alone, so
+//               every map with the same recipes, item multiset, agent count and border kind
+//               runs on it -- all `*_tomato` levels share one, and so does a user-made map with
+//               those recipes on a box that has no hipcc (the generic library takes 7.3 us).
 //   HdrK  generic build: both kinds are scalar loads from the kernel arguments.
 // (Tried and dropped in round 2: the header spread over the lanes of three VGPRs, one
 // v_readlane per access.  Slower -- 7.68 us per step at 4 096 envs against 6.97 us with kernarg
@@ -158,9 +162,15 @@ struct HdrC {
 #define OC_F(T, name) __device__ __forceinline__ constexpr T name() const { return OC_SPEC_HDR.name; }
 #define OC_A(T, name) __device__ __forceinline__ constexpr T name(int i) const { return OC_SPEC_HDR.name[i]; }
 #define OC_A64(name) __device__ __forceinline__ constexpr uint64_t name(int i) const { return OC_SPEC_HDR.name[i]; }
+#ifdef OC_SPEC_GEOMETRY
+#define OC_GF(T, name) OC_F(T, name)
+#define OC_GA(T, name) OC_A(T, name)
+#define OC_GA64(name) OC_A64(name)
+#else
 #define OC_GF(T, name) __device__ __forceinline__ T name() const { return k.name; }
 #define OC_GA(T, name) __device__ __forceinline__ T name(int i) const { return k.name[i]; }
 #define OC_GA64(name) __device__ __forceinline__ uint64_t name(int i) const { return k.name[i]; }
+#endif
   OC_HDR_FIELDS(OC_F, OC_A, OC_A64, OC_GF, OC_GA, OC_GA64)
 #undef OC_F
 #undef OC_A
@@ -1976,14 +1986,16 @@ int oc_abi_version(void) { return OC_ABI_VERSION; }
 const char *oc_last_error(void) { return g_err; }
 
 int oc_is_specialized(void) {
-#ifdef OC_SPECIALIZED
-  return 1;
+#if defined(OC_SPECIALIZED) && defined(OC_SPEC_GEOMETRY)
+  return 2;   // a "level" library: structure and geometry folded
+#elif defined(OC_SPECIALIZED)
+  return 1;   // a "structure" library: geometry at run time
 #else
   return 0;
 #endif
 }
 
-int oc_level_spec_source(const int32_t *b, int32_t n_words, char *buf, int32_t buf_size) {
+int oc_level_spec_source(const int32_t *b, int32_t n_words, int32_t with_geometry, char *buf, int32_t buf_size) {
   LevelHdr full, h;
   RunCfg run;
   const char *msg = build_header(b, n_words, full, run);
@@ -1991,7 +2003,8 @@ int oc_level_spec_source(const int32_t *b, int32_t n_words, char *buf, int32_t b
     snprintf(g_err, sizeof(g_err), "oc_level_spec_source: %s", msg);
     return OC_E_BADARG;
   }
-  h = structure_of(full);   // the geometry stays a run-time argument of the specialised kernels
+  // a "structure" library keeps the geometry a run-time argument: blank it in the header
+  h = with_geometry ? full : structure_of(full);
   if (!buf || buf_size < 64) return fail(OC_E_BADARG, "oc_level_spec_source: buffer too small");
   // LevelHdr holds 32-bit words and three pairs of 64-bit planes; emit it field by field
   // in declaration order as one aggregate initialiser.
@@ -2050,11 +2063,15 @@ int oc_level_create(const int32_t *b, int32_t n_words, oc_level_t **out) {
   }
 #ifdef OC_SPECIALIZED
   {
+#ifdef OC_SPEC_GEOMETRY
+    const LevelHdr spec = OC_SPEC_HDR, mine = h;
+#else
     const LevelHdr spec = OC_SPEC_HDR, mine = structure_of(h);
+#endif
     if (memcmp(&spec, &mine, sizeof(LevelHdr)) != 0) {
       delete lv;
-      return fail(OC_E_BADARG, "oc_level_create: this library is specialised for a different level structure "
-                               "(recipes, item multiset, agent count, border kind)");
+      return fail(OC_E_BADARG, "oc_level_create: this library is specialised for a different level (a \"level\" "
+                               "library) or level structure (recipes, item multiset, agent count, border kind)");
     }
   }
 #endif

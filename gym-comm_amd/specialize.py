@@ -1,18 +1,27 @@
-"""Per-level kernel specialisation.
+"""Kernel specialisation.
 
 The generic liboc_hip.so reads a level's static tables (map bit-planes, goal sets,
 item types, shaping lookup programs) from kernel arguments at run time.  For a level
 that is stepped millions of times it pays to fold them into the code instead: the same
 source (csrc/oc_kernels.hip) compiled with ``-DOC_SPECIALIZED`` and a generated header
 that holds the level as a ``constexpr LevelHdr`` gives straight-line kernels with no
-scalar loads, no uniform branches and fully unrolled loops.  The result is an ordinary
-shared library exporting the same C ABI (include/oc_hip.h) that refuses any other level.
+uniform branches and fully unrolled loops.  The result is an ordinary shared library
+exporting the same C ABI (include/oc_hip.h).  Two flavours:
 
+  "level" library      (``-DOC_SPEC_GEOMETRY``) folds everything, the map included: the
+                       fastest code (3.64 us per step, tomato-2 x 4096 envs), for ONE map;
+  "structure" library  folds what the recipes, the item multiset, the agent count and the
+                       border kind fix; the map (size, tiles, positions) stays a run-time
+                       argument (3.82 us).  It serves EVERY map of that structure -- e.g. a
+                       user-made map with the Salad recipe on a box that has no hipcc, which
+                       the generic library would step at 7.3 us.
+
+``load_for`` picks, in this order: the cached level library; the cached structure library;
+a level library compiled now (hipcc present, no profiler attached); the generic library.
 Libraries are cached in csrc/_spec/ under a hash of (generated header, kernel source,
-C headers), so they are built once -- by ``__graft_entry__.build()`` for the BASELINE
-levels, or on first use wherever hipcc is available -- and travel with the repo snapshot.
-max_num_timesteps and the ALLERGIC flags stay run-time arguments and do not select a
-specialisation; the subtask order does (it fixes bit positions).
+C headers, flags) -- built by ``__graft_entry__.build()`` for every shipped level (both
+flavours) and travelling with the repo snapshot.  max_num_timesteps, the ALLERGIC flags
+and the subtask order stay run-time arguments and select nothing.
 """
 import ctypes
 import hashlib
@@ -48,12 +57,13 @@ def clean_env():
     return env
 
 
-def spec_header_text(blob) -> str:
-    """The generated header for a level blob (host only, no GPU needed)."""
+def spec_header_text(blob, geometry=True) -> str:
+    """The generated header for a level blob (host only, no GPU needed): the whole level
+    (`geometry`, a "level" library) or its structure alone."""
     L = _lib.load()
     blob = np.ascontiguousarray(blob, dtype=np.int32)
     buf = ctypes.create_string_buffer(16384)
-    n = L.oc_level_spec_source(blob.ctypes.data_as(_I32P), int(blob.size), buf, len(buf))
+    n = L.oc_level_spec_source(blob.ctypes.data_as(_I32P), int(blob.size), 1 if geometry else 0, buf, len(buf))
     if n < 0:
         _lib.check(n, "oc_level_spec_source", L)
     return buf.value.decode()
@@ -71,26 +81,28 @@ def _source_digest():
     return h
 
 
-def spec_key(blob) -> str:
+def spec_key(blob, geometry=True) -> str:
     h = _source_digest()
-    h.update(spec_header_text(blob).encode())
+    h.update(b"level" if geometry else b"structure")
+    h.update(spec_header_text(blob, geometry).encode())
     return h.hexdigest()[:16]
 
 
-def spec_lib_path(blob) -> str:
-    return os.path.join(SPEC_DIR, "liboc_spec_%s.so" % spec_key(blob))
+def spec_lib_path(blob, geometry=True) -> str:
+    return os.path.join(SPEC_DIR, "liboc_spec_%s.so" % spec_key(blob, geometry))
 
 
-def ensure(blob, verbose=False):
-    """Return the path of the specialised library for this level, building it if needed.
-    Returns None when it is not cached and hipcc is unavailable."""
-    text = spec_header_text(blob)
-    h = _source_digest()
-    h.update(text.encode())
-    key = h.hexdigest()[:16]
+def ensure(blob, verbose=False, geometry=True, compile=True):
+    """Return the path of the specialised library of this level (`geometry`: its level library,
+    else its structure library), building it if needed.  Returns None when it is not cached and
+    cannot / may not be compiled (`compile=False`, no hipcc, a profiler attached)."""
+    text = spec_header_text(blob, geometry)
+    key = spec_key(blob, geometry)
     path = os.path.join(SPEC_DIR, "liboc_spec_%s.so" % key)
     if os.path.exists(path):
         return path
+    if not compile:
+        return None
     if profiler_attached():
         # hipcc execs clang and lld; under rocprofv3 this process has already initialised the
         # GPU (the profiler's preloaded library does) and those exec hops would inherit its
@@ -112,7 +124,7 @@ def ensure(blob, verbose=False):
     os.replace(tmp_hdr, hdr)
     tmp_lib = "%s.%s.tmp" % (path, uniq)
     cmd = [hipcc, "--offload-arch=" + _build.ARCH] + _build.FLAGS
-    cmd += ["-DOC_SPECIALIZED", '-DOC_SPEC_FILE="%s"' % hdr]
+    cmd += ["-DOC_SPECIALIZED", '-DOC_SPEC_FILE="%s"' % hdr] + (["-DOC_SPEC_GEOMETRY"] if geometry else [])
     cmd += [os.path.join(_build.CSRC, s) for s in _build.SOURCES] + ["-o", tmp_lib]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -127,12 +139,22 @@ def ensure(blob, verbose=False):
 
 def load_for(blob, mode="auto", verbose=False):
     """The library to use for a level: ('spec' | 'generic', typed CDLL).
-    mode: True (must specialise), False (generic), 'auto' (specialise when possible)."""
+    mode: True (must specialise), False (generic), 'auto' (specialise when possible),
+    'structure' (the structure library: tests, measurements).  Order for True / 'auto': cached
+    level library, cached structure library, a level library compiled now, generic."""
     if os.environ.get("OC_SPECIALIZE") == "0" and mode == "auto":
         mode = False
+    if os.environ.get("OC_SPECIALIZE") == "structure" and mode == "auto":
+        mode = "structure"
     if mode is False:
         return "generic", _lib.load()
-    path = ensure(blob, verbose=verbose)
+    if mode == "structure":
+        path = ensure(blob, verbose=verbose, geometry=False)
+        if path is None:
+            raise _lib.OcError("no cached structure library for this level and hipcc is unavailable")
+        return "spec", _lib.load(path)
+    path = (ensure(blob, geometry=True, compile=False) or ensure(blob, geometry=False, compile=False)
+            or ensure(blob, verbose=verbose, geometry=True))
     if path is None:
         if mode is True:
             raise _lib.OcError("no cached specialisation for this level and hipcc is unavailable")

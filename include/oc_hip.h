@@ -140,13 +140,18 @@ OC_API const char *oc_last_error(void);
  * (gym_cooking/envs/overcooked_environment.py:180-206). */
 OC_API int oc_level_create(const int32_t *blob, int32_t n_words, oc_level_t **out);
 OC_API int oc_level_destroy(oc_level_t *lv);
-/* Per-level specialisation (optional, see gym-comm_amd/specialize.py).  The same source
- * compiled with -DOC_SPECIALIZED and a generated header yields a library whose kernels
- * have the level's static tables folded in as compile-time constants; it exports this
- * same ABI and its oc_level_create() refuses any other level.
- *   oc_level_spec_source: write that generated header (C++ text) for a blob; returns its
- *   length, or a negative OC_E_* code.  Host only -- needs no GPU. */
-OC_API int oc_level_spec_source(const int32_t *blob, int32_t n_words, char *buf, int32_t buf_size);
+/* Specialisation (optional, see gym-comm_amd/specialize.py).  The same source compiled with
+ * -DOC_SPECIALIZED and a generated header yields a library whose kernels have a level's static
+ * data folded in as compile-time constants; it exports this same ABI.  Two flavours:
+ *   "structure" library  folds what the recipes, the item multiset, the agent count and the
+ *       border kind fix; the map itself (size, tiles, positions) stays a run-time argument.
+ *       oc_level_create() accepts ANY map of that structure.
+ *   "level" library (additionally -DOC_SPEC_GEOMETRY)  folds the map as well: fastest, one map.
+ *   oc_level_spec_source: write the generated header (C++ text) for a blob -- with_geometry != 0
+ *   for a level library; returns its length, or a negative OC_E_* code.  Host only.
+ *   oc_is_specialized: 0 generic, 1 structure library, 2 level library. */
+OC_API int oc_level_spec_source(const int32_t *blob, int32_t n_words, int32_t with_geometry, char *buf,
+                                int32_t buf_size);
 OC_API int oc_is_specialized(void);
 /* Where the state tensor keeps a subtask's bits.  The kernels order subtasks canonically
  * (Chop / Merge sorted by kind, goal object and food, then the Deliver subtasks in the blob's

@@ -730,10 +730,18 @@ OC_EXPORT void oc_oracle_step(void *h, const int32_t *actions, int32_t *reward, 
 /* TEST ONLY: put a freshly reset env into a hand-made state of single-content objects, so that
  * corners random play practically never reaches (e.g. the World.remove alias, world.py:239-247)
  * can be staged.  agents [A][3] = x, y, held item id (-1 = empty hands); items [M][3] = x, y,
- * state_index (a held item sits on its holder's cell whatever x, y say). */
-OC_EXPORT void oc_oracle_debug_set(void *h, const int32_t *agents, const int32_t *items) {
+ * state_index (a held item sits on its holder's cell whatever x, y say); completed / goalcnt [S]
+ * (NULL = zeros): completed_subtasks and goal_objects_count, which must agree with the objects
+ * (a chopped food means its Chop subtask was rewarded) or the state is one the reference
+ * cannot be in. */
+OC_EXPORT void oc_oracle_debug_set(void *h, const int32_t *agents, const int32_t *items, const int32_t *completed,
+                                   const int32_t *goalcnt) {
   Env *e = (Env *)h;
   env_reset(e); /* object i = item i; keys by type in world order */
+  for (int s = 0; s < e->S; s++) { /* the bookkeeping that goes with the staged objects */
+    e->completed[s] = completed ? completed[s] : 0;
+    e->goalcnt[s] = goalcnt ? goalcnt[s] : 0;
+  }
   for (int i = 0; i < e->M; i++) {
     e->objs[i].x = items[3 * i];
     e->objs[i].y = items[3 * i + 1];

@@ -76,7 +76,7 @@ def lib():
         L.oc_oracle_batch_snapshot.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64] + [_I32P] * 7
         L.oc_oracle_batch_reset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, _I32P]
         L.oc_oracle_pyset_order.argtypes = [_I32P, ctypes.c_int, _I32P]
-        L.oc_oracle_debug_set.argtypes = [ctypes.c_void_p, _I32P, _I32P]
+        L.oc_oracle_debug_set.argtypes = [ctypes.c_void_p, _I32P, _I32P, _I32P, _I32P]
         _lib = L
     return _lib
 
@@ -164,12 +164,15 @@ class OracleEnv:
             a = np.ascontiguousarray(cells, dtype=np.int32)
             lib().oc_oracle_set_placement(self._h, _p32(a))
 
-    def debug_set(self, agents, items):
+    def debug_set(self, agents, items, completed=None, goal_count=None):
         """TEST ONLY: stage a state of single-content objects (oc_oracle_debug_set): agents
-        [A][3] = x, y, held item (-1); items [M][3] = x, y, state_index."""
+        [A][3] = x, y, held item (-1); items [M][3] = x, y, state_index; completed / goal_count
+        [S] (default zeros)."""
         a = np.ascontiguousarray(agents, dtype=np.int32).reshape(self.A, 3)
         it = np.ascontiguousarray(items, dtype=np.int32).reshape(self.M, 3)
-        lib().oc_oracle_debug_set(self._h, _p32(a), _p32(it))
+        cs = np.ascontiguousarray(completed if completed is not None else np.zeros(self.S), dtype=np.int32)
+        gc = np.ascontiguousarray(goal_count if goal_count is not None else np.zeros(self.S), dtype=np.int32)
+        lib().oc_oracle_debug_set(self._h, _p32(a), _p32(it), _p32(cs), _p32(gc))
 
     def step(self, actions):
         act = np.ascontiguousarray(actions, dtype=np.int32)

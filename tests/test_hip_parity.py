@@ -146,7 +146,7 @@ def test_wrapper_matches_reference_golden(run, fused):
 CASES = SEEDED_CASES
 
 
-@pytest.mark.parametrize("spec", [False, True], ids=["generic", "spec"])
+@pytest.mark.parametrize("spec", [False, True, "structure"], ids=["generic", "spec", "structure"])
 @pytest.mark.parametrize("level,A,T", CASES, ids=["%s-a%d" % (c[0], c[1]) for c in CASES])
 def test_step_matches_oracle_seeded(level, A, T, spec, oracle_lib):
     """Seeded action streams, every env different, auto-reset on: full state compare with
@@ -181,7 +181,7 @@ def test_step_matches_oracle_seeded(level, A, T, spec, oracle_lib):
     assert tot_d > 0 and tot_r > 0
 
 
-@pytest.mark.parametrize("spec", [False, True], ids=["generic", "spec"])
+@pytest.mark.parametrize("spec", [False, True, "structure"], ids=["generic", "spec", "structure"])
 @pytest.mark.parametrize("level,T,C,radius", [("open-divider_tomato", 100, 2, 2),
                                               ("full-divider_salad", 120, 5, 1),
                                               ("open-divider_tl", 200, 3, 3)])
@@ -668,12 +668,16 @@ def test_action_sources_agree(oracle_lib):
         e.multi_step(None, ego_pairs=big)           # no source for the partner
 
 
-def _stage(env, lv, agents, items):
+def _stage(env, lv, agents, items, completed):
     """Put every env of the batch into a hand-made state of single-content objects: the twin of
-    OracleEnv.debug_set (agents [x, y, held item or -1], items [x, y, state_index])."""
+    OracleEnv.debug_set (agents [x, y, held item or -1], items [x, y, state_index], completed [S]
+    = completed_subtasks = goal_objects_count of the staged objects)."""
     env.reset()
     w = env.state.cpu().numpy().copy()                 # [A+M+2][n] packed words (include/oc_hip.h)
     A = lv.num_agents
+    bits_ = sum(1 << env.subtask_slot[s] for s, c in enumerate(completed) if c)
+    w[A + lv.num_items] = bits_
+    w[A + lv.num_items + 1] = bits_
     for a, (x, y, h) in enumerate(agents):
         w[a] = (w[a] & ~0xFFF) | x | (y << 4) | ((h + 1) << 8 if h >= 0 else 0)
     for i, (x, y, st) in enumerate(items):
@@ -698,18 +702,21 @@ def test_world_remove_alias_corner_staged(spec, oracle_lib):
     lv = compiler.compile_level("open-divider_tl", 3, 100)
     assert [t for t, _, _ in lv.items] == [0, 1, 3, 3]                 # Tomato, Lettuce, Plate, Plate
     items = [[0, 4, 1], [6, 1, 0], [6, 5, 0], [5, 6, 0]]               # the Tomato chopped, on Counter (0, 4)
+    # ... which means Chop(Tomato) has been rewarded and its goal object counted
+    done_ = [1 if (s.kind == compiler.KIND_CHOP and s.args == ("Tomato",)) else 0 for s in lv.subtasks]
+    assert sum(done_) == 1
     n = 130
     acts = np.tile(np.array([[2], [4], [4]], np.int32), (1, n))         # agent 0 presses LEFT into the counter
     for hold0, hold2, expect_err in ((2, 3, 2), (3, 2, 0)):
         agents = [[1, 4, hold0], [3, 3, -1], [1, 4, hold2]]
         env = _env(lv, n, auto_reset=False, specialize_level=spec)
-        _stage(env, lv, agents, items)
+        _stage(env, lv, agents, items, done_)
         ora = oracle_lib.OracleBatch(lv.blob, n)
         for i in range(n):
             e = oracle_lib.OracleEnv.__new__(oracle_lib.OracleEnv)
             e.A, e.M, e.S, e._h = ora.A, ora.M, ora.S, ora._handles[i]
             try:
-                e.debug_set(agents, items)
+                e.debug_set(agents, items, done_, done_)
             finally:
                 e._h = None
         assert_snapshots_equal(env.snapshot(), ora.snapshot_all(), "staged state")
@@ -732,12 +739,14 @@ def test_custom_map_runs_on_the_library_of_its_structure(oracle_lib):
     from gym_comm_amd import compiler, levels, specialize
     text = "---t---\n/     -\n-  l  p\n*     -\n-     -\n--p----\n\nSalad\n\n1 1\n5 4"      # 7 x 6, our own
     lv = compiler.compile_level(levels.parse_level_text("custom-7x6_salad", text), 2, 80)
-    assert specialize.spec_key(lv.blob) == specialize.spec_key(compiler.compile_level("open-divider_salad", 2, 80).blob)
+    assert specialize.spec_key(lv.blob, geometry=False) == \
+        specialize.spec_key(compiler.compile_level("open-divider_salad", 2, 80).blob, geometry=False)
+    assert not os.path.exists(specialize.spec_lib_path(lv.blob))       # no level library for this map
     n, steps, C = 900, 240, 3
     rng = np.random.default_rng(5)
     acts = scripted_then_random(rng, "custom", steps, 2, n)
-    env = _env(lv, n, auto_reset=True, specialize_level=True, num_communication=C, fow_radius=1)
-    assert env.kernel_flavour == "spec"
+    env = _env(lv, n, auto_reset=True, specialize_level="structure", num_communication=C, fow_radius=1)
+    assert env.kernel_flavour == "spec" and env._L.oc_is_specialized() == 1
     ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
     tot = 0
     for k in range(steps):

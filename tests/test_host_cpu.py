@@ -260,7 +260,7 @@ def test_specialised_library_refuses_other_levels():
     if path is None:
         pytest.skip("hipcc unavailable and no cached specialisation")
     lib = _lib.load(path)
-    assert lib.oc_is_specialized() == 1 and _lib.load().oc_is_specialized() == 0
+    assert lib.oc_is_specialized() == 2 and _lib.load().oc_is_specialized() == 0      # a "level" library
     rc, msg = _create(lib, b.blob)
     assert rc == -1 and "different level" in msg
     rc, msg = _create(lib, a.blob)
@@ -368,8 +368,10 @@ def test_specialised_libraries_are_keyed_by_structure_not_by_map(tmp_path):
     recipe, agent count or border kind does not."""
     import torch
     from gym_comm_amd import _lib, compiler as C, specialize
-    key = lambda lv: specialize.spec_key(lv.blob)
+    key = lambda lv: specialize.spec_key(lv.blob, geometry=False)      # the structure library
     base = C.compile_level("open-divider_tomato", 2, 100)
+    # (the "level" flavour folds the map as well: one library per map)
+    assert specialize.spec_key(C.compile_level("full-divider_tomato", 2, 100).blob) != specialize.spec_key(base.blob)
     assert key(C.compile_level("full-divider_tomato", 2, 100)) == key(base)
     assert key(C.compile_level("partial-divider_tomato", 2, 50)) == key(base)
     mine = "---t---\n/     -\n-  l  p\n*     -\n-     -\n--p----\n\nSimpleTomato\n\n1 1\n5 4"   # 7 x 6, our own
@@ -377,10 +379,14 @@ def test_specialised_libraries_are_keyed_by_structure_not_by_map(tmp_path):
     lv = C.compile_level("mine", 2, 100, level_dir=str(tmp_path))
     assert [t for t, _, _ in lv.items] == [t for t, _, _ in base.items] and lv.height == 6
     assert key(lv) == key(base)
-    path = specialize.ensure(base.blob)
+    path = specialize.ensure(base.blob, geometry=False)
     if path is not None:
-        rc, msg = _create(_lib.load(path), lv.blob)
+        lib = _lib.load(path)
+        assert lib.oc_is_specialized() == 1
+        rc, msg = _create(lib, lv.blob)
         assert rc == (0 if torch.cuda.is_available() else -2), msg
+        rc, msg = _create(lib, C.compile_level("open-divider_salad", 2, 100).blob)
+        assert rc == -1 and "structure" in msg
     assert key(C.compile_level("open-divider_tomato", 3, 100)) != key(base)        # agent count
     assert key(C.compile_level("open-divider_salad", 2, 100)) != key(base)         # recipes
     assert key(C.compile_level("random-open-divider_tomato", 2, 100)) != key(base)  # items / open border
