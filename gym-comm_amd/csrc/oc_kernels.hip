@@ -1574,6 +1574,12 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     asm volatile("" ::"s"(tb.dist), "s"(p.obs), "s"(p.timestep), "s"(p.reward), "s"(p.done),
                  "s"(p.sparse), "s"(p.auto_reset), "s"(p.R.inv_T), "s"(p.R.inv_max_path));
     if constexpr (XO) asm volatile("" ::"s"(p.opt.ep_return), "s"(p.opt.ep_length));
+#if defined(OC_SPECIALIZED) && !defined(OC_SPEC_GEOMETRY)
+    // structure library: the map's geometry is a kernel argument; the first things the step
+    // needs of it -- row length, tile planes, the Delivery tile -- are fetched here as well
+    asm volatile("" ::"s"(L.W()), "s"(L.ncells()), "s"(L.max_path()), "s"(L.cell_lo(0)), "s"(L.cell_hi(0)),
+                 "s"(L.deliv_pos(0)));
+#endif
     // episode statistics: the running return / length and the previous step's done flag are
     // loaded now, with the state, and consumed after the last store of the step
     double ep_ret = 0.0;
