@@ -390,3 +390,54 @@ def test_specialised_libraries_are_keyed_by_structure_not_by_map(tmp_path):
     assert key(C.compile_level("open-divider_tomato", 3, 100)) != key(base)        # agent count
     assert key(C.compile_level("open-divider_salad", 2, 100)) != key(base)         # recipes
     assert key(C.compile_level("random-open-divider_tomato", 2, 100)) != key(base)  # items / open border
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("oc_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_byte_accounting():
+    """roofline.frac is formed with the bytes the layout moves (never above SURVEY's
+    int32-per-field figure, which stays a labelled secondary rate)."""
+    b = _load_bench()
+    for A, M, S, C, wrapper, survey in ((2, 4, 3, 2, True, 536), (2, 4, 9, 2, True, 680), (3, 4, 6, 2, False, 372)):
+        rd, wr = b.layout_bytes_per_env_step(A, M, S, C, wrapper)
+        assert b.survey_bytes_per_env_step(A, M, S, C, wrapper) == survey       # BASELINE.md section 4
+        assert rd == 4 * (A + M + 2) + 4 * (4 if wrapper else A)
+        assert rd + wr < survey
+    # int8 observation rows: both accountings use 1-byte observation elements
+    rd8, wr8 = b.layout_bytes_per_env_step(2, 4, 3, 2, True, obs_elem=1)
+    assert wr8 == 296.75 - 3 * 2 * (22 + 3 + 4)
+    assert b.survey_bytes_per_env_step(2, 4, 3, 2, True, obs_elem=1) == 536 - 3 * 2 * (23 + 3 + 4)
+
+
+def test_bench_never_reports_one_gpu_for_an_n_gpu_request(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher starts N ranks through torch.distributed.run
+    and relays rank 0's line ONLY if it says n_gpus == N (VERDICT r1 / ADVICE r1)."""
+    import json
+    import subprocess
+    from types import SimpleNamespace
+    b = _load_bench()
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return SimpleNamespace(returncode=0, stdout=(json.dumps({"n_gpus": seen["report"], "value": 1.0}) + "\n").encode())
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    args = b.parse(["--gpus", "4", "--steps", "20", "--warmup", "5"])
+    seen["report"] = 4
+    assert b.spawn_ranks(args) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert json.loads(capsys.readouterr().out.strip())["n_gpus"] == 4
+    seen["report"] = 1                               # a run that silently measured one GPU
+    assert b.spawn_ranks(args) != 0
+    assert capsys.readouterr().out.strip() == ""
