@@ -367,9 +367,14 @@ __device__ __forceinline__ double timestep_of(int t, const RunCfg &R) {
 // until the end-of-kernel write-back, so the write-back overlaps the rest of the launch
 // instead of trailing it.  tools/store_probe.hip (76 row stores per env): 10.4 -> 7.9 us
 // per launch at n = 131072, 4.4 -> 3.7 us at 32768; sc0 / nt change nothing.  In the
-// kernels: salad-2 x 32768 6.84 -> 5.88 us, tomato-2 x 131072 11.1 -> 10.0 us, but
-// 4.56 -> 4.66 us at n = 4096 (a lone wave per CU waits longer for its last store), so
-// the launcher picks the write-through variant (template bool WT) from 8 192 envs on.
+// kernels (round 1, v5): salad-2 x 32768 6.84 -> 5.88 us, tomato-2 x 131072 11.1 -> 10.0 us, but
+// 4.56 -> 4.66 us at n = 4096 -- back then every wave still ended on a wait for its own stores
+// (the metrics slot was a load + store), and a lone wave per CU waited longer for a written-
+// through one.  Since v11 no wave waits for its stores, and round 2 re-measured
+// (tools/wt_threshold.sh): write-through is never slower, 3.64 -> 3.51 us at n = 4096, 3.53 ->
+// 3.46 us at 512, 3.44 -> 3.43 us at 64, salad-2 x 4096 3.89 -> 3.74 us.  The launcher picks the
+// write-through variant (template bool WT) at every batch size; OC_WRITE_THROUGH=0 restores
+// write-back stores.
 template <int AUX>
 struct RowsT {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -1714,9 +1719,10 @@ int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_
 }
 
 bool write_through(int64_t n) {
-  // sc1 stores (see RowsT) from 8 192 envs on (tools/wt_sweep.sh: 5.26 -> 5.06 us there); OC_WRITE_THROUGH=0/1 overrides (tuning / tests)
+  // sc1 stores (see RowsT) at every batch size (tools/wt_threshold.sh); OC_WRITE_THROUGH=0/1 overrides (tuning / tests)
   static const int forced = getenv("OC_WRITE_THROUGH") ? atoi(getenv("OC_WRITE_THROUGH")) : -1;
-  return forced >= 0 ? forced == 1 : n >= 8192;
+  (void)n;
+  return forced >= 0 ? forced == 1 : true;
 }
 
 bool tables_in_lds(int64_t) {
