@@ -400,7 +400,10 @@ struct RowsT {
   }
 };
 using Rows = RowsT<0>;          // loads and default-policy stores
-constexpr int AUX_WT = 16;      // sc1
+#ifndef OC_AUX_WT
+#define OC_AUX_WT 16            // sc1; -DOC_AUX_WT=<bits> via OC_HIP_EXTRA_FLAGS to try other store policies
+#endif
+constexpr int AUX_WT = OC_AUX_WT;
 
 // calculate_reward_shaping for sim agents 0 and 1 (overcooked_environment.py:272-397),
 // given the agents' cells, the item cells, the completed flags and, per Deliver subtask, the
