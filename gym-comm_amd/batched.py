@@ -40,7 +40,7 @@ class BatchedOvercooked:
                  communication_on=True, ego_led=False, fow_radius=2, ego_agent_idx=0,
                  device="cuda", subtask_order=None, placements=None, level_dir=None,
                  max_num_subtasks=14, auto_reset=True, track_metrics=True, specialize_level="auto",
-                 seed=0, placement_mode="rng", obs_dtype=torch.int32, episode_stats=False):
+                 seed=0, placement_mode="rng", obs_dtype=torch.int32, episode_stats=False, play=False):
         cfg = {"ALLERGIC": False, "BLIND": False, "CAN_MOVE": True}   # missing CAN_MOVE = True
         self.ego_config = dict(cfg, **(ego_config or {}))
         self.partner_config = dict(cfg, **(partner_config or {}))
@@ -51,7 +51,7 @@ class BatchedOvercooked:
                 level, num_agents, max_num_timesteps, max_num_subtasks,
                 ego_allergic=self.ego_config["ALLERGIC"],
                 partner_allergic=self.partner_config["ALLERGIC"],
-                subtask_order=subtask_order, placements=placements, level_dir=level_dir)
+                subtask_order=subtask_order, placements=placements, level_dir=level_dir, play=play)
         lv = self.level
         if not lv.hip_supported:
             raise ValueError("level %r: more than three items of one type, or more than 16 distinct "

@@ -370,6 +370,7 @@ class CompiledLevel:
     allergic_mask: int
     counters: List[Tuple[int, int]] = field(default_factory=list)   # Counter tiles, world order
     scatter_items: List[int] = field(default_factory=list)          # item ids placed at random per reset
+    play: bool = False                                              # arglist.play (interact.py:44-47,52,66-67)
     blob: np.ndarray = field(default=None, repr=False)
 
     @property
@@ -462,7 +463,7 @@ def scatter_item_ids(spec: L.LevelSpec) -> List[int]:
 def compile_level(level, num_agents: int, max_num_timesteps: int = 100,
                   max_num_subtasks: int = 14, ego_allergic: bool = False,
                   partner_allergic: bool = False, subtask_order=None, placements=None,
-                  level_dir: Optional[str] = None) -> CompiledLevel:
+                  level_dir: Optional[str] = None, play: bool = False) -> CompiledLevel:
     spec = level if isinstance(level, L.LevelSpec) else L.load_level(level, level_dir)
     if not (1 <= num_agents <= MAX_AGENTS):
         raise ValueError("num_agents must be 1..%d" % MAX_AGENTS)
@@ -495,7 +496,8 @@ def compile_level(level, num_agents: int, max_num_timesteps: int = 100,
         max_num_timesteps=int(max_num_timesteps), cells=cells, dist=dist,
         agents=list(spec.agent_starts[:num_agents]), items=items, subtasks=subtasks,
         recipes=list(spec.recipes), pair_types=pair_types, delivery=delivery,
-        allergic_mask=allergic, counters=list(spec.counters), scatter_items=scatter_item_ids(spec))
+        allergic_mask=allergic, counters=list(spec.counters), scatter_items=scatter_item_ids(spec),
+        play=bool(play))
     if len(lv.counters) > 64:
         raise ValueError("too many Counter tiles")
     lv.blob = build_blob(lv)
@@ -515,7 +517,8 @@ def build_blob(lv: CompiledLevel) -> np.ndarray:
     b = np.zeros(off, dtype=np.int32)
     b[0:16] = [MAGIC, VERSION, lv.width, lv.height, lv.num_agents, lv.num_items,
                lv.num_subtasks, lv.max_num_timesteps, lv.max_path, lv.allergic_mask,
-               len(lv.pair_types), len(lv.delivery), len(lv.counters), len(lv.scatter_items), 0, 0]
+               len(lv.pair_types), len(lv.delivery), len(lv.counters), len(lv.scatter_items),
+               1 if lv.play else 0, 0]
     b[16:26] = [sec["cells"], sec["dist"], sec["agents"], sec["items"], sec["subtasks"],
                 sec["pair"], sec["delivery"], off, sec["counters"], sec["scatter"]]
     b[sec["cells"]:sec["cells"] + n] = lv.cells.reshape(-1)

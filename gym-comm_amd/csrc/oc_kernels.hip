@@ -97,6 +97,7 @@ struct RunCfg {
   // bit of the caller's subtask s; only the completed_subtasks observation rows need it.
   uint32_t slot_identity;
   uint32_t slot4[OC_MAX_SUBTASKS / 4];
+  uint32_t play;   // arglist.play: the "playable" branches of interact() (utils/interact.py:44-47,52,66-67)
 };
 
 #ifdef OC_STAMPS
@@ -798,12 +799,18 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
     const bool do_deliver = nf && holding && at_deliv && held_multi && !held_fresh;   // :25-30, core.py:232-237
     const bool mergeable = !two_plates && !any_fresh;                                   // core.py:240-257
     const bool do_merge = nf && holding && !at_deliv && tgt_any && mergeable;         // :33-46
-    const bool chop_here = ct == OC_CUTBOARD && !held_multi && held_fresh;            // :52
+    // arglist.play (uniform): a merge is put straight onto the counter (:44-47), a fresh food is
+    // put DOWN on a Cutboard (:52) and chopped where it lies by an empty-handed press (:66-67)
+    const bool play = R.play != 0;
+    const bool chop_here = ct == OC_CUTBOARD && !held_multi && held_fresh && !play;   // :52
     const bool do_chop = nf && holding && !at_deliv && !tgt_any && chop_here;         // :52-54
     const bool do_drop = nf && holding && !at_deliv && !tgt_any && !chop_here;        // :56-57
-    const bool do_pick = nf && !holding && !at_deliv && tgt_any && !((R.allergic >> a) & 1);  // :62-71, agent.py:296-298
-    const bool put = do_deliver || do_drop;
-    const bool take = do_merge || do_pick;
+    const bool chop_there = nf && !holding && !at_deliv && tgt_any && play && ct == OC_CUTBOARD &&
+                            (tgt_or & IW_CHOP) != 0;                                  // :66-67 (a fresh food is always alone)
+    const bool do_pick = nf && !holding && !at_deliv && tgt_any && !chop_there &&
+                         !((R.allergic >> a) & 1);                                    // :62-71, agent.py:296-298
+    const bool put = do_deliver || do_drop || (do_merge && play);
+    const bool take = (do_merge && !play) || do_pick;
     const int newg = min(holding ? e.ahp[a] - 1 : 7, igrp(tgt_or));  // only used when `take` (then tgt_any)
     // the merged Object: smallest item id as group, re-inserted under a new name = last in
     // world order (world.py:236-237), union of the type sets
@@ -857,9 +864,9 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
     // (merge / pick up), object fields (merge)
     const int mask_m = ((do_move || put) ? IW_POS : 0) | (put ? IW_HOLD : 0) | (do_merge ? OBJ<DUP> : 0) |
                        (do_chop ? IW_CHOP : 0);
-    const int mask_t = (take ? (IW_POS | IW_HOLD) : 0) | (do_merge ? OBJ<DUP> : 0);
+    const int mask_t = (take ? (IW_POS | IW_HOLD) : 0) | (do_merge ? OBJ<DUP> : 0) | (chop_there ? IW_CHOP : 0);
     const int val_m = tp | IW_CHOP | objf;
-    const int val_t = pa | hold_code | objf;
+    const int val_t = pa | hold_code | objf | IW_CHOP;
 #pragma unroll
     for (int i = 0; i < M; i++) {
       const int sel = mine[i] ? mask_m : (tgt[i] ? mask_t : 0);
@@ -1625,7 +1632,9 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     e.err |= (bad_mv | bad_cm) ? OC_ERR_ACTION : 0;
     ShapeIn<2> sin;
     ShapeLoads<2> sld;
-    env_step<A, M, DUP>(L, p.R, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
+    RunCfg Rl = p.R;
+    if constexpr (!XO) Rl.play = 0;   // (the plain variant is only launched for play == 0)
+    env_step<A, M, DUP>(L, Rl, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     Out(p.done, p.n, 1, i).st(0, done);
@@ -1826,6 +1835,7 @@ const char *build_header(const int32_t *b, int32_t n_words, LevelHdr &h, RunCfg 
   run.inv_T = run.T ? 1.0 / (double)run.T : 0.0;
   run.inv_max_path = 1.0 / (double)b[OC_LV_MAX_PATH];
   run.allergic = (uint32_t)b[OC_LV_ALLERGIC];
+  run.play = (uint32_t)(b[OC_LV_FLAGS] & OC_FLAG_PLAY);
   const int32_t *cells = b + b[OC_LV_OFF_CELLS];
   const int32_t *ag = b + b[OC_LV_OFF_AGENTS], *it = b + b[OC_LV_OFF_ITEMS];
   const int32_t *st = b + b[OC_LV_OFF_SUBTASKS], *pr = b + b[OC_LV_OFF_PAIR], *dl = b + b[OC_LV_OFF_DELIV];
@@ -2294,7 +2304,7 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   if (ot < 0 || ot > 2) return fail(OC_E_BADARG, "oc_multi_step: obs_int8 must be 0 (int32), 1 (int8) or 2 (float32)");
   const bool wt = write_through(n);
   const bool std_cfg = cfg->communication_on && !cfg->ego_led && cfg->can_move_mask == 3 &&
-                       cfg->ego_agent_idx == 0 && cfg->obs.blind_mask == 0;
+                       cfg->ego_agent_idx == 0 && cfg->obs.blind_mask == 0 && !lv->run.play;
   const bool xo = o.ep_return || o.ego_pairs || o.alt_pairs || o.alt_rng || !std_cfg;
 #define OC_MS_X(MM, DD, XX)                                                           \
   do {                                                                                \

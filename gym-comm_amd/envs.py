@@ -100,10 +100,6 @@ class OvercookedEnvironment:
         ``t``, ``world``, ``sim_agents``, ``completed_subtasks``, ``display()``, ``str()``,
         episode_recorder.py:15-85) and the batch is stepped by its owner."""
         self.arglist = arglist
-        if _arg(arglist, "play", False):
-            # interact() takes other branches with arglist.play (merges onto the counter, chops on
-            # pick-up: utils/interact.py:44-47,52,66-67); that interactive mode is not built
-            raise ValueError("arglist.play=True (interactive play mode) is not supported")
         ego = dict(_arg(arglist, "ego_config", {}) or {})
         partner = dict(_arg(arglist, "partner_config", {}) or {})
         self._index, self._view = int(_index), bool(_view)
@@ -116,7 +112,8 @@ class OvercookedEnvironment:
             communication_on=_arg(arglist, "communication_on", False),
             ego_led=_arg(arglist, "ego_led", False), fow_radius=_arg(arglist, "fow_radius", 2),
             device=device, subtask_order=subtask_order, placements=placements,
-            level_dir=level_dir, auto_reset=False, track_metrics=False)
+            level_dir=level_dir, auto_reset=False, track_metrics=False,
+            play=bool(_arg(arglist, "play", False)))     # interact.py:44-47,52,66-67
         lv = self._b.level
         self._stale, self._pending_words = False, None
         self._v_world = SimpleNamespace(width=lv.width, height=lv.height,
@@ -568,7 +565,8 @@ def _make_multi_env_class():
                 ego_led=_arg(arglist, "ego_led", False),
                 fow_radius=_arg(arglist, "fow_radius", 2), ego_agent_idx=ego_agent_idx,
                 device=device, subtask_order=subtask_order, placements=placements,
-                level_dir=level_dir, auto_reset=False, track_metrics=False)
+                level_dir=level_dir, auto_reset=False, track_metrics=False,
+                play=bool(_arg(arglist, "play", False)))
             self.base_env = OvercookedEnvironment(arglist, _batch=self._b)
             lv = self._b.level
             self.lA = len(NAV_ACTIONS)

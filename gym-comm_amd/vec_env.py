@@ -248,8 +248,6 @@ class OvercookedVecEnv(_VecEnvBase):
                  track_episode_stats=True, use_graph=False, **batched_kw):
         if _arg(arglist, "num_agents") != 2:
             raise ValueError("the gym_comm wrapper drives exactly 2 agents")
-        if _arg(arglist, "play", False):
-            raise ValueError("arglist.play=True (interactive play mode) is not supported")
         self.arglist = arglist
         self.terminal_obs = bool(terminal_obs)
         self.track_episode_stats = bool(track_episode_stats)
@@ -264,7 +262,7 @@ class OvercookedVecEnv(_VecEnvBase):
             ego_led=_arg(arglist, "ego_led", False), fow_radius=_arg(arglist, "fow_radius", 2),
             ego_agent_idx=ego_agent_idx, device=device, subtask_order=subtask_order,
             level_dir=level_dir, auto_reset=True, seed=seed,
-            episode_stats=self.track_episode_stats, **batched_kw)
+            episode_stats=self.track_episode_stats, play=bool(_arg(arglist, "play", False)), **batched_kw)
         lv = self._b.level
         obs_space, act_space = make_spaces(lv.width, lv.height, lv.num_subtasks, self._b.C)
         super().__init__(num_envs, obs_space, act_space)

@@ -33,7 +33,8 @@ enum {
   OC_LV_NDELIV = 11,    /* number of Delivery tiles */
   OC_LV_NCOUNTERS = 12, /* number of Counter tiles (targets of random item placement) */
   OC_LV_NSCATTER = 13,  /* items placed on random Counters at every reset (random-* levels) */
-  /* 14..15 reserved */
+  OC_LV_FLAGS = 14,     /* run flags: bit 0 = arglist.play (OC_FLAG_PLAY) */
+  /* 15 reserved */
   OC_LV_OFF_CELLS = 16,    /* W*H words: cell type, index y*W+x */
   OC_LV_OFF_DIST = 17,     /* (W*H)^2 words: D[a*W*H + b] */
   OC_LV_OFF_AGENTS = 18,   /* A * {x, y} */
@@ -46,6 +47,11 @@ enum {
   OC_LV_OFF_SCATTER = 25,  /* NSCATTER item indices, in the level file's letter order */
   OC_LV_HEADER_WORDS = 32
 };
+
+/* arglist.play ("playable" interact(): a merge lands on the counter, a fresh food put on a Cutboard
+ * is chopped by the next empty-handed press instead of when it is put down,
+ * gym_cooking/utils/interact.py:44-47,52,66-67) */
+#define OC_FLAG_PLAY 1
 
 /* cell types (gym_cooking/utils/core.py:66-133) */
 enum { OC_FLOOR = 0, OC_COUNTER = 1, OC_CUTBOARD = 2, OC_DELIVERY = 3 };

@@ -54,7 +54,7 @@ typedef struct {
 
 typedef struct {
   /* static */
-  int W, H, A, M, S, T, max_path, allergic, npair, ndeliv;
+  int W, H, A, M, S, T, max_path, allergic, npair, ndeliv, play;
   const int32_t *cells, *dist, *agent0, *item0, *pair, *deliv;
   Sub sub[OC_MAX_SUBTASKS];
   int32_t *blob;
@@ -287,7 +287,7 @@ static void agent_move_to(Env *e, int a, int x, int y) {
   }
 }
 
-/* interact (utils/interact.py:4-75), arglist.play == False */
+/* interact (utils/interact.py:4-75), both settings of arglist.play */
 static void interact(Env *e, int a) {
   if (e->adx[a] == 0 && e->ady[a] == 0) return; /* :12 */
   int tx = e->ax[a] + e->adx[a], ty = e->ay[a] + e->ady[a];
@@ -319,9 +319,15 @@ static void interact(Env *e, int a) {
         /* agent.acquire(obj) -> holding.merge(obj) (agent.py:305, core.py:210-218) */
         for (int i = 0; i < obj->n; i++) held->c[held->n++] = obj->c[i];
         world_insert(e, hid);
+        if (e->play) { /* :44-47 "if playable version, merge onto counter first" */
+          held->x = tx; /* gs.acquire(agent.holding) */
+          held->y = ty;
+          held->is_held = 0; /* agent.release() */
+          e->ahold[a] = -1;
+        }
       }
     } else { /* :50-59 */
-      if (gs == OC_CUTBOARD && needs_chopped(e, held)) {
+      if (gs == OC_CUTBOARD && needs_chopped(e, held) && !e->play) { /* :52 */
         e->items[held->c[0]].state += 1; /* Object.chop -> Food.update_state */
       } else {
         held->x = tx; /* gs.acquire(obj) */
@@ -333,6 +339,9 @@ static void interact(Env *e, int a) {
   } else { /* :62-75 */
     if (is_occupied(e, tx, ty) && gs != OC_DELIVERY) {
       int oid = get_unheld_object_at(e, tx, ty);
+      if (gs == OC_CUTBOARD && needs_chopped(e, &e->objs[oid]) && e->play) {
+        e->items[e->objs[oid].c[0]].state += 1; /* :66-67: chopped where it lies, not picked up */
+      } else
       /* gs.release(); agent.acquire(obj): no-op for an ALLERGIC agent (agent.py:296-298) */
       if (!((e->allergic >> a) & 1)) {
         Obj *obj = &e->objs[oid];
@@ -658,6 +667,7 @@ OC_EXPORT void *oc_oracle_create(const int32_t *blob, int n_words) {
   e->W = b[OC_LV_W]; e->H = b[OC_LV_H]; e->A = b[OC_LV_A]; e->M = b[OC_LV_M];
   e->S = b[OC_LV_S]; e->T = b[OC_LV_T]; e->max_path = b[OC_LV_MAX_PATH];
   e->allergic = b[OC_LV_ALLERGIC]; e->npair = b[OC_LV_NPAIR]; e->ndeliv = b[OC_LV_NDELIV];
+  e->play = b[OC_LV_FLAGS] & OC_FLAG_PLAY;
   e->cells = b + b[OC_LV_OFF_CELLS];
   e->dist = b + b[OC_LV_OFF_DIST];
   e->agent0 = b + b[OC_LV_OFF_AGENTS];

@@ -38,7 +38,7 @@ def compile_for(st, **kw):
     return compiler.compile_level(
         level, st["num_agents"], st["max_num_timesteps"],
         ego_allergic=bool(e.get("ALLERGIC")), partner_allergic=bool(p.get("ALLERGIC")),
-        subtask_order=st["subtasks"], **kw)
+        subtask_order=st["subtasks"], play=bool(st.get("play", False)), **kw)
 
 
 @pytest.fixture(scope="session")

@@ -123,12 +123,12 @@ class Purposeful:
         return self.plan[ai].popleft()
 
 
-def run_base(level, A, T, tapes, ego_config=None, partner_config=None):
+def run_base(level, A, T, tapes, ego_config=None, partner_config=None, play=False):
     """tapes: list of (kind, spec).  Returns dict of arrays + static json."""
-    arg = H.make_arglist(level, A, T, ego_config=ego_config, partner_config=partner_config)
+    arg = H.make_arglist(level, A, T, ego_config=ego_config, partner_config=partner_config, play=play)
     env = H.base_env(arg)
     static = H.static_tables(env)
-    static.update(level=level, num_agents=A, max_num_timesteps=T,
+    static.update(level=level, num_agents=A, max_num_timesteps=T, play=bool(play),
                   ego_config=arg.ego_config, partner_config=arg.partner_config,
                   hashseed=os.environ.get("PYTHONHASHSEED", "unset"))
     S = len(env.all_subtasks)
@@ -240,7 +240,7 @@ def run_wrapper(name, level, T, steps, seed, kind="purpose", ego_agent_idx=0, **
     base = env.base_env
     static = H.static_tables(base)
     C = arg.num_communication
-    static.update(level=level, num_agents=2, max_num_timesteps=T,
+    static.update(level=level, num_agents=2, max_num_timesteps=T, play=bool(cfg.get("play", False)),
                   ego_config=arg.ego_config, partner_config=arg.partner_config,
                   num_communication=C, communication_on=arg.communication_on,
                   ego_led=arg.ego_led, fow_radius=arg.fow_radius,
@@ -398,6 +398,28 @@ DUP_LEVELS = {
 }
 
 
+def main_play(summary):
+    """arglist.play = True: the "playable" branches of interact() (utils/interact.py:44-47,52,
+    66-67) -- a merge lands on the counter, a fresh food is put down on a Cutboard and chopped by
+    the next empty-handed press."""
+    for level, A, T, tapes in [("open-divider_tomato", 2, 150, [("purpose", (6000, 90))]),
+                               ("full-divider_salad", 2, 200, [("purpose", (8000, 91))]),
+                               ("partial-divider_tl", 3, 150, [("purpose", (5000, 92))])]:
+        out, sr, nd = run_base(level, A, T, tapes, play=True)
+        fn = "pbase_%s_a%d.npz" % (level, A)
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["t"])), "sum_reward": sr, "episodes": nd}
+        print(fn, summary[fn], flush=True)
+    for name, level, T, steps, seed, kw in [("play_tomato_r2", "open-divider_tomato", 150, 5000, 150, {"play": True}),
+                                            ("play_salad_c3", "open-divider_salad", 200, 6000, 151,
+                                             {"play": True, "num_communication": 3, "fow_radius": 1})]:
+        out, nd = run_wrapper(name, level, T, steps, seed, **kw)
+        fn = "pwrap_%s.npz" % name
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        summary[fn] = {"steps": int(len(out["done"])), "episodes": nd}
+        print(fn, summary[fn], flush=True)
+
+
 def main_dup(summary):
     H.use_custom_levels(DUP_LEVELS)
     jobs = [("custom-two_tomatoes", 2, 200, [("purpose", (7000, 80))]),
@@ -499,6 +521,13 @@ def main():
             out = run_fow(level, 100, 1500, seed, radius)
             np.savez_compressed(os.path.join(HERE, "fow_%s.npz" % name), **out)
             print("fow_%s.npz" % name, out["maps"].shape, int(out["completed"].sum()))
+        return
+    if "--play-only" in sys.argv:
+        with open(os.path.join(HERE, "SUMMARY.json")) as f:
+            summary = json.load(f)
+        main_play(summary)
+        with open(os.path.join(HERE, "SUMMARY.json"), "w") as f:
+            json.dump(summary, f, indent=1, sort_keys=True)
         return
     if "--dup-only" in sys.argv:
         with open(os.path.join(HERE, "SUMMARY.json")) as f:

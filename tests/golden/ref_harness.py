@@ -107,7 +107,7 @@ def quiet():
 
 def make_arglist(level, num_agents, T, ego_config=None, partner_config=None,
                  num_communication=2, communication_on=True, ego_led=False,
-                 fow_radius=2):
+                 fow_radius=2, play=False):
     cfg = {"ALLERGIC": False, "BLIND": False, "CAN_MOVE": True}
     e = dict(cfg); e.update(ego_config or {})
     p = dict(cfg); p.update(partner_config or {})
@@ -115,7 +115,7 @@ def make_arglist(level, num_agents, T, ego_config=None, partner_config=None,
         level=level, num_agents=num_agents, max_num_timesteps=T,
         max_num_subtasks=14, seed=1, with_image_obs=False,
         beta=1.3, alpha=0.01, tau=2, cap=75, main_cap=100,
-        play=False, record=False,
+        play=play, record=False,
         model1=None, model2=None, model3=None, model4=None,
         ego_config=e, partner_config=p,
         num_communication=num_communication, communication_on=communication_on,

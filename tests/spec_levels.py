@@ -20,7 +20,9 @@ SPEC_GOLDEN = ["base_open-divider_tomato_a2.npz", "base_full-divider_salad_a2.np
                # levels that repeat a content type (dup mode)
                "cbase_dup_two_tomatoes_a2.npz", "cbase_dup_two_tomatoes_small_a3.npz",
                "cbase_dup_two_lettuces_salad_a2.npz", "cwrap_dup_two_lettuces_salad_c3.npz",
-               "cwrap_dup_two_tomatoes_small_r1.npz"]
+               "cwrap_dup_two_tomatoes_small_r1.npz",
+               # arglist.play = True (a run-time flag: the same libraries)
+               "pbase_open-divider_tomato_a2.npz", "pbase_partial-divider_tl_a3.npz", "pwrap_play_salad_c3.npz"]
 
 
 # fixtures whose level (canonical subtask order) the seeded dup-mode test steps

@@ -15,8 +15,8 @@ from spec_levels import SEEDED_CASES, SPEC_GOLDEN
 pytestmark = pytest.mark.gpu
 
 # rbase_/rwrap_: random-* levels; cbase_/cwrap_: our own maps run through the reference
-BASE = golden_files("base_") + golden_files("rbase_") + golden_files("cbase_")
-WRAP = golden_files("wrap_") + golden_files("rwrap_") + golden_files("cwrap_")
+BASE = golden_files("base_") + golden_files("rbase_") + golden_files("cbase_") + golden_files("pbase_")
+WRAP = golden_files("wrap_") + golden_files("rwrap_") + golden_files("cwrap_") + golden_files("pwrap_")
 # (c*_dup_*: maps that repeat a content type -- multiset objects, goal counts above 1, CPython's
 # set order in the shaping terms; the library's "dup" kernels)
 

@@ -10,8 +10,8 @@ from conftest import compile_for, golden_files, load_golden
 
 # rbase_/rwrap_: random-* levels; cbase_/cwrap_: our own maps (OnionSalad, shared subtasks,
 # two Delivery tiles) run through the reference
-BASE = golden_files("base_") + golden_files("rbase_") + golden_files("cbase_")
-WRAP = golden_files("wrap_") + golden_files("rwrap_") + golden_files("cwrap_")
+BASE = golden_files("base_") + golden_files("rbase_") + golden_files("cbase_") + golden_files("pbase_")
+WRAP = golden_files("wrap_") + golden_files("rwrap_") + golden_files("cwrap_") + golden_files("pwrap_")
 
 
 def _pack(cells):
