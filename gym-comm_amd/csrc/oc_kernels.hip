@@ -702,7 +702,8 @@ __device__ __forceinline__ void shaping_sum(const Hdr &L, const ShapeIn<B> &in, 
 // Everything up to done/reward, plus the address formation and the loads of the reward
 // shaping (shaping_issue_*); the caller stores what it has to store and then calls
 // shaping_lookup(L, quot, sin, sld, sq) and, after its stores, shaping_sum(L, sin, sq, ...).
-template <int A, int M, bool DUP>
+// PM: arglist.play known at compile time (0 = off, 1 = on) or a run-time flag (2: R.play)
+template <int A, int M, bool DUP, int PM>
 __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const uint8_t *__restrict__ dist,
                                          const uint32_t *__restrict__ probe,
                                          Env<A, M, DUP> &e, const int (&act_in)[A], int &reward, int &done,
@@ -801,7 +802,7 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
     const bool do_merge = nf && holding && !at_deliv && tgt_any && mergeable;         // :33-46
     // arglist.play (uniform): a merge is put straight onto the counter (:44-47), a fresh food is
     // put DOWN on a Cutboard (:52) and chopped where it lies by an empty-handed press (:66-67)
-    const bool play = R.play != 0;
+    const bool play = PM == 2 ? R.play != 0 : PM == 1;
     const bool chop_here = ct == OC_CUTBOARD && !held_multi && held_fresh && !play;   // :52
     const bool do_chop = nf && holding && !at_deliv && !tgt_any && chop_here;         // :52-54
     const bool do_drop = nf && holding && !at_deliv && !tgt_any && !chop_here;        // :56-57
@@ -1262,7 +1263,7 @@ struct StepArgs {
 };
 
 // (leading scalars: preloaded kernel arguments, see k_multi_step)
-template <int A, int M, bool LDS, bool WT, bool DUP>
+template <int A, int M, bool LDS, bool WT, bool DUP, bool PLAY>
 __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32_t *const actions_,
                                               int64_t *const metrics_, const int64_t n_, const int32_t launch_,
                                               const int32_t T_, const void *const tables_,
@@ -1303,7 +1304,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
 #endif
     RunCfg R = p.R;
     R.T = T_;   // the preloaded copy
-    env_step<A, M, DUP>(L, R, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
+    env_step<A, M, DUP, PLAY ? 1 : 0>(L, R, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     ShapeQ<B> sq;
@@ -1632,9 +1633,8 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     e.err |= (bad_mv | bad_cm) ? OC_ERR_ACTION : 0;
     ShapeIn<2> sin;
     ShapeLoads<2> sld;
-    RunCfg Rl = p.R;
-    if constexpr (!XO) Rl.play = 0;   // (the plain variant is only launched for play == 0)
-    env_step<A, M, DUP>(L, Rl, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
+    // (the plain variant is only launched for play == 0; the general one reads the flag)
+    env_step<A, M, DUP, XO ? 2 : 0>(L, p.R, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     Out(p.done, p.n, 1, i).st(0, done);
@@ -2211,18 +2211,22 @@ int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_
              metrics, placement, rng, n, auto_reset};
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
   const bool D_ = lv->hdr.has_dup != 0;
+  const bool pl = lv->run.play != 0;
   const size_t lds = (size_t)lv->n16 * 16;
   if (tables_in_lds(n)) {
-#define OC_X(AA, MM, DD) return launch_st(k_step<AA, MM, true, false, DD>, a, n, stream, lds)
+#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, true, false, DD, true>, a, n, stream, lds) \
+                                   : launch_st(k_step<AA, MM, true, false, DD, false>, a, n, stream, lds)
     OC_FOR_AM(OC_X)
 #undef OC_X
   } else {
     if (write_through(n)) {
-#define OC_X(AA, MM, DD) return launch_st(k_step<AA, MM, false, true, DD>, a, n, stream, 0)
+#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, false, true, DD, true>, a, n, stream, 0) \
+                                   : launch_st(k_step<AA, MM, false, true, DD, false>, a, n, stream, 0)
       OC_FOR_AM(OC_X)
 #undef OC_X
     }
-#define OC_X(AA, MM, DD) return launch_st(k_step<AA, MM, false, false, DD>, a, n, stream, 0)
+#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, false, false, DD, true>, a, n, stream, 0) \
+                                   : launch_st(k_step<AA, MM, false, false, DD, false>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   }
