@@ -267,7 +267,7 @@ class BatchedOvercooked:
         """Image-style fog-of-war observation of both viewers
         (get_partial_observability_FOW, overcooked_env.py:161-202).  Returns
         (maps int8 [2][7][W][H][n], holding int8 [2][n]).  The kernel writes four consecutive
-        int8 rows of an env per dword ([2][ceil(7WH/4)][n] int32, include/oc_hip.h); the
+        cells of a plane of an env per dword ([2][7*ceil(WH/4)][n] int32, include/oc_hip.h); the
         [2][7][W][H][n] result is one re-layout copy of that -- `packed=True` returns the
         kernel's tensor itself."""
         lv = self.level
@@ -282,10 +282,10 @@ class BatchedOvercooked:
                        "oc_obs_image", self._L)
         if packed:
             return self._image, self._holding
-        rows = 7 * lv.width * lv.height
-        q = self._image_words
-        img = self._image.view(torch.int8).view(2, q, self.n, 4).permute(0, 1, 3, 2).reshape(2, 4 * q, self.n)
-        return img[:, :rows].reshape(2, 7, lv.width, lv.height, self.n), self._holding
+        cells = lv.width * lv.height
+        q = self._image_words // 7
+        img = self._image.view(torch.int8).view(2, 7, q, self.n, 4).permute(0, 1, 2, 4, 3).reshape(2, 7, 4 * q, self.n)
+        return img[:, :, :cells].reshape(2, 7, lv.width, lv.height, self.n), self._holding
 
     def completed_subtasks(self):
         """completed_subtasks of every env as int32 [S][n] (from the packed state)."""

@@ -1367,7 +1367,7 @@ __global__ void __launch_bounds__(256) k_obs(const ObsArgs p) {
 struct ImageArgs {
   LevelHdr L;
   const int32_t *state;
-  int32_t *out;       // [2][ceil(7*W*H / 4)][n]: four consecutive rows of an env per dword
+  int32_t *out;       // [2][7][ceil(W*H / 4)][n]: four consecutive cells of a plane per dword
   int8_t *holding;    // [2][n]
   int64_t n;
   int32_t radius;
@@ -1375,13 +1375,19 @@ struct ImageArgs {
 
 // OvercookedMultiEnv.get_partial_observability_FOW for both viewers
 // (gym_comm/envs/overcooked_env.py:161-202; the image-style observation the reference
-// defines but does not call).  Row r = (k*W + x)*H + y of viewer v holds plane k at cell (x, y):
-// plane 0 the tile type, planes 1.. "agent i stands here" (:183-185 -- with 3+ agents these
-// overwrite the content planes, as in the reference), planes 3 + channel the contents (Food:
-// state_index + 1, Plate: 1); cells farther than `radius` (manhattan) from the viewer are -1 in
-// every plane.  Rows are int8; a lane packs FOUR consecutive rows of its env into one dword
-// (little-endian, zero padded past the last row), so a wave stores 256 contiguous bytes per
-// instruction: 172 dword stores per viewer-pair and wave at 7x7 instead of 686 byte stores.
+// defines but does not call).  Plane k of viewer v at cell (x, y) -- the reference's
+// map[k][x][y] -- is byte (x*H + y) of the plane: plane 0 the tile type, planes 1.. "agent i
+// stands here" (:183-185 -- with 3+ agents these overwrite the content planes, as in the
+// reference), planes 3 + channel the contents (Food: state_index + 1, Plate: 1); cells farther
+// than `radius` (manhattan) from the viewer are -1 in every plane.  A lane packs FOUR consecutive
+// cells of a plane of its env into one dword (little-endian, zero padded past the last cell), so
+// a wave stores 256 contiguous bytes per instruction.
+// Work per env is organised by QUAD, not by byte: the fog bytes of a quad are formed once per
+// viewer and reused by its seven planes; an agent / item contributes to the one quad its cell
+// falls into (a compare and a select per quad); a plane's dword is then one bit-field insert
+// (fog bytes win) and one store.  ~1 100 VALU + 182 stores per wave at 7x7 -- the first version
+// walked the 343 bytes of a viewer one by one, ~120 instructions each (56 us per launch at 4 096
+// envs; this one: see DESIGN.md).
 template <int A, int M, bool DUP>
 __global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
   OC_HDR_LOAD(p);
@@ -1395,44 +1401,66 @@ __global__ void __launch_bounds__(256) k_obs_image(const ImageArgs p) {
   Env<A, M, DUP> e;
   unpack<A, M, DUP>(e, w);
   const int W = L.W(), H = L.H();
-  const int rows = 7 * W * H, R4 = (rows + 3) >> 2;
+  const int ncell = W * H, Q = (ncell + 3) >> 2;
   const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(2 * R4 * p.n * 4), 0x00020000);
-  int k = 0, x = 0, y = 0;   // (plane, cell) of row r, advanced incrementally (uniform)
-  for (int r4 = 0; r4 < R4; r4++) {
-    unsigned pk[2] = {0u, 0u};
+      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(2 * 7 * Q * p.n * 4), 0x00020000);
+  // per agent / item: the quad its cell (x-major index x*H + y) falls into and its byte there
+  int aq[A], abyte[A];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      if (4 * r4 + b < rows) {   // uniform
-        const int cell = x | (y << 4);
-        int val = k == 0 ? cell_type(L, y * W + x) : 0;
-        if (k >= 3) {   // uniform; the last writer in world order wins (:171-178) -- it only matters when
-          int best = -1;  // two items of one type share a cell (dup levels)
+  for (int a = 0; a < A; a++) {
+    const int c = (int)__umul24((unsigned)px(e.ap[a]), (unsigned)H) + py(e.ap[a]);
+    aq[a] = c >> 2;
+    abyte[a] = 8 * (c & 3);
+  }
+  int iq[M], ishift[M], ival[M];
 #pragma unroll
-          for (int m = 0; m < M; m++)
-            if (item_type(L, m) + 3 == k) {   // uniform
-              const bool hit = ipos(e.iw[m]) == cell && (e.iw[m] & IW_SEQ) > best;
-              val = hit ? (k == 3 + OC_PLATE ? 1 : ichop(e.iw[m]) + 1) : val;
-              best = hit ? (e.iw[m] & IW_SEQ) : best;
-            }
-        }
+  for (int m = 0; m < M; m++) {
+    const int pos = ipos(e.iw[m]);
+    const int c = (int)__umul24((unsigned)px(pos), (unsigned)H) + py(pos);
+    iq[m] = c >> 2;
+    ishift[m] = 8 * (c & 3);
+    ival[m] = item_type(L, m) == OC_PLATE ? 1 : ichop(e.iw[m]) + 1;
+    // the last writer in world order wins (:171-178): an item gives way to a later one of its
+    // type on the same cell (only in levels that repeat a type)
+    bool later = false;
 #pragma unroll
-        for (int a = 0; a < A; a++)
-          if (k == a + 1) val = e.ap[a] == cell ? 1 : val;   // uniform test
+    for (int o = 0; o < M; o++)
+      if (o != m && item_type(L, o) == item_type(L, m))   // uniform
+        later |= ipos(e.iw[o]) == pos && (e.iw[o] & IW_SEQ) > (e.iw[m] & IW_SEQ);
+    iq[m] = later ? -1 : iq[m];
+  }
+  const int vx[2] = {px(e.ap[0]), px(e.ap[1])}, vy[2] = {py(e.ap[0]), py(e.ap[1])};
+  int x = 0, y = 0;   // cell of the quad's first byte, advanced incrementally (uniform)
+  for (int q = 0; q < Q; q++) {
+    unsigned fog[2] = {0u, 0u}, tile = 0u;
 #pragma unroll
-        for (int v = 0; v < 2; v++) {
-          const bool fog = iabs(x - px(e.ap[v])) + iabs(y - py(e.ap[v])) > p.radius;
-          pk[v] |= (unsigned)((fog ? -1 : val) & 255) << (8 * b);
-        }
-        if (++y == H) {
-          y = 0;
-          if (++x == W) x = 0, k++;
-        }
+    for (int b = 0; b < 4; b++)
+      if (4 * q + b < ncell) {   // uniform
+        tile |= (unsigned)cell_type(L, y * W + x) << (8 * b);   // uniform: SALU
+#pragma unroll
+        for (int v = 0; v < 2; v++)
+          fog[v] |= (int)sad_u32((unsigned)x, (unsigned)vx[v], sad_u32((unsigned)y, (unsigned)vy[v], 0u)) > p.radius
+                        ? 0xFFu << (8 * b) : 0u;
+        if (++y == H) y = 0, x++;
       }
-    }
 #pragma unroll
-    for (int v = 0; v < 2; v++)
-      __builtin_amdgcn_raw_buffer_store_b32((int)pk[v], rsrc, (int)i * 4, (int)((v * R4 + r4) * p.n * 4), AUX_WT);
+    for (int k = 0; k < 7; k++) {
+      unsigned val = k == 0 ? tile : 0u;
+      if (k >= 3) {
+#pragma unroll
+        for (int m = 0; m < M; m++)
+          if (item_type(L, m) + 3 == k)   // uniform
+            val |= iq[m] == q ? (unsigned)ival[m] << ishift[m] : 0u;
+      }
+      if (k >= 1 && k <= A) {   // agent k-1 stands here: 1, over whatever the plane held at that cell
+        const int a = k - 1;
+        val = aq[a] == q ? (val & ~(0xFFu << abyte[a])) | (1u << abyte[a]) : val;
+      }
+#pragma unroll
+      for (int v = 0; v < 2; v++)
+        __builtin_amdgcn_raw_buffer_store_b32((int)(val | fog[v]), rsrc, (int)i * 4,
+                                              (int)(((v * 7 + k) * Q + q) * p.n * 4), AUX_WT);
+    }
   }
   p.holding[i] = e.ahp[0] != 0;
   p.holding[p.n + i] = e.ahp[1] != 0;
@@ -2262,7 +2290,7 @@ int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *comm, cons
   }
 }
 
-int32_t oc_image_words(const oc_level_t *lv) { return lv ? (7 * lv->hdr.ncells + 3) / 4 : 0; }
+int32_t oc_image_words(const oc_level_t *lv) { return lv ? 7 * ((lv->hdr.ncells + 3) / 4) : 0; }
 
 int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int32_t *out, int8_t *holding,
                  int64_t n, void *stream) {

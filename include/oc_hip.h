@@ -206,11 +206,12 @@ OC_API int oc_obs(const oc_level_t *lv, const int32_t *state, const int32_t *com
 
 /* OvercookedMultiEnv.get_partial_observability_FOW for both viewers
  * (gym_comm/envs/overcooked_env.py:161-202), the image-style fog-of-war observation.
- * Row r = (k*W + x)*H + y of a viewer = plane k at cell (x, y), int8, -1 = fogged; four
- * consecutive rows of one env travel in one dword:
- *   out      int32 [2][oc_image_words()][n]  byte b of word q = row 4q + b (zero past 7*W*H)
+ * Plane k of a viewer at cell (x, y) -- the reference's map[k][x][y] -- is int8 byte x*H + y of
+ * the plane, -1 = fogged; four consecutive cells of a plane of one env travel in one dword:
+ *   out      int32 [2][7][Q][n], Q = ceil(W*H / 4) = oc_image_words() / 7; byte b of word q =
+ *            cell 4q + b (zero past W*H)
  *   holding  int8 [2][n]                     (agent 0 holds, agent 1 holds) */
-OC_API int32_t oc_image_words(const oc_level_t *lv);                 /* ceil(7*W*H / 4) */
+OC_API int32_t oc_image_words(const oc_level_t *lv);                 /* 7 * ceil(W*H / 4) */
 OC_API int oc_obs_image(const oc_level_t *lv, const int32_t *state, int32_t radius, int32_t *out,
                         int8_t *holding, int64_t n, void *stream);
 
