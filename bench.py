@@ -105,6 +105,9 @@ def parse(argv=None):
     p.add_argument("--obs-dtype", default="int32", choices=sorted(ELEM),
                    help="observation rows: int32 (SURVEY 8(d) accounting), int8 (4x fewer bytes) or float32")
     p.add_argument("--hidden", type=int, default=64, help="closed-loop: width of the two policy MLPs")
+    p.add_argument("--waves-per-64", type=int, default=0, choices=[0, 1, 4],
+                   help="launch hint of the fused step: 0 = the library decides (split launch up to 16384 envs), "
+                        "1 = one wave per 64 envs, 4 = split launch (include/oc_hip.h, oc_step_opts)")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -296,7 +299,8 @@ def main():
         env = BatchedOvercooked(args.level, num_agents=args.agents, num_envs=n,
                                 max_num_timesteps=args.T, num_communication=args.comm,
                                 communication_on=True, fow_radius=2, device=dev, auto_reset=True,
-                                obs_dtype=getattr(torch, args.obs_dtype), seed=seed)
+                                obs_dtype=getattr(torch, args.obs_dtype), seed=seed,
+                                waves_per_64=args.waves_per_64)
         gen = torch.Generator(device=dev).manual_seed(seed)
         if wrapper:
             hi = torch.tensor([4, args.comm, 4, args.comm], device=dev).view(1, 4, 1)
@@ -430,6 +434,7 @@ def main():
                        "max_num_timesteps": args.T, "launch": "hipgraph" if use_graph else "eager",
                        "obs_dtype": "float32" if closed else args.obs_dtype,
                        "kernel_flavour": env.kernel_flavour,
+                       "waves_per_64_envs": env.launch_waves_per_64 if wrapper else 1,
                        "parallelism": "env-sharded x%d" % world},
             "agent_steps_per_sec": value * lv.num_agents,
             "timing": {"what": "median over back-to-back blocks of `steps` steps (`reps` of them, "

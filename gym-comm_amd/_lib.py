@@ -9,12 +9,12 @@ import os
 from . import build as _build
 
 _I32P = ctypes.POINTER(ctypes.c_int32)
-ABI_VERSION = 3          # include/oc_hip.h: OC_ABI_VERSION
+ABI_VERSION = 4          # include/oc_hip.h: OC_ABI_VERSION
 
 SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destroy",
            "oc_level_spec_source", "oc_is_specialized", "oc_level_subtask_info",
            "oc_metrics_slots", "oc_state_words", "oc_obs_rows", "oc_reset", "oc_step", "oc_obs",
-           "oc_obs_image", "oc_image_words", "oc_multi_step", "oc_random_actions"]
+           "oc_obs_image", "oc_image_words", "oc_multi_step", "oc_multi_step_waves", "oc_random_actions"]
 
 
 class ObsCfg(ctypes.Structure):
@@ -33,7 +33,7 @@ class StepOpts(ctypes.Structure):
     _fields_ = [("ep_return", ctypes.c_void_p), ("ep_length", ctypes.c_void_p),
                 ("ego_pairs", ctypes.c_void_p), ("alt_pairs", ctypes.c_void_p),
                 ("alt_rng", ctypes.c_void_p), ("alt_played", ctypes.c_void_p),
-                ("pairs_int64", ctypes.c_int32)]
+                ("pairs_int64", ctypes.c_int32), ("waves_per_64", ctypes.c_int32)]
 
 
 class OcError(RuntimeError):
@@ -83,6 +83,8 @@ def _declare(L):
     L.oc_multi_step.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
                                 ctypes.c_int32, vp, vp, vp, ctypes.POINTER(StepOpts), ctypes.c_int64, vp]
     L.oc_random_actions.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
+    L.oc_multi_step_waves.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    L.oc_multi_step_waves.restype = ctypes.c_int32
     for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_level_subtask_info",
               "oc_reset", "oc_step",
               "oc_obs", "oc_obs_image", "oc_multi_step", "oc_random_actions"):

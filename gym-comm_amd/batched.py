@@ -40,7 +40,8 @@ class BatchedOvercooked:
                  communication_on=True, ego_led=False, fow_radius=2, ego_agent_idx=0,
                  device="cuda", subtask_order=None, placements=None, level_dir=None,
                  max_num_subtasks=14, auto_reset=True, track_metrics=True, specialize_level="auto",
-                 seed=0, placement_mode="rng", obs_dtype=torch.int32, episode_stats=False, play=False):
+                 seed=0, placement_mode="rng", obs_dtype=torch.int32, episode_stats=False, play=False,
+                 waves_per_64=0):
         cfg = {"ALLERGIC": False, "BLIND": False, "CAN_MOVE": True}   # missing CAN_MOVE = True
         self.ego_config = dict(cfg, **(ego_config or {}))
         self.partner_config = dict(cfg, **(partner_config or {}))
@@ -66,6 +67,11 @@ class BatchedOvercooked:
         self.A, self.M, self.S = lv.num_agents, lv.num_items, lv.num_subtasks
         self.C = int(num_communication)
         self.auto_reset = bool(auto_reset)
+        # launch hint of the fused step (include/oc_hip.h, oc_step_opts.waves_per_64): 0 = the
+        # library decides, 1 = one wave per 64 envs, 4 = split launch; results are identical
+        if waves_per_64 not in (0, 1, 4):
+            raise ValueError("waves_per_64 must be 0 (auto), 1 or 4")
+        self.waves_per_64 = int(waves_per_64)
         blob = np.ascontiguousarray(lv.blob, dtype=np.int32)
         # per-level specialised kernels when available (specialize.py), else the generic library
         self.kernel_flavour, self._L = specialize.load_for(blob, specialize_level)
@@ -134,6 +140,11 @@ class BatchedOvercooked:
         if h is not None and h.value:
             self._L.oc_level_destroy(h)
             self._h = None
+
+    @property
+    def launch_waves_per_64(self):
+        """Waves per 64 envs the fused step is launched with (1, or 4 = split launch)."""
+        return int(self._L.oc_multi_step_waves(self.n, self.waves_per_64))
 
     # -- helpers ---------------------------------------------------------------
     def _on_device(self):
@@ -244,7 +255,7 @@ class BatchedOvercooked:
         if a is None:       # every pointer but the action sources is fixed for the life of the env
             dp = lambda t: 0 if t is None else t.data_ptr()
             self._ms_opts = _lib.StepOpts(dp(self.ep_return) or None, dp(self.ep_length) or None,
-                                          None, None, None, None, 0)
+                                          None, None, None, None, 0, self.waves_per_64)
             a = self._ms_args = [self._h, dp(self.state), dp(self.comm), 0, ctypes.byref(self._wrap_cfg),
                                  dp(self.obs), dp(self.timestep), dp(self.shaped_reward), dp(self.done),
                                  dp(self.reward), 0, dp(self.metrics), dp(self.placement), dp(self.rng),

@@ -1533,21 +1533,39 @@ struct MultiArgs {
 // both players CAN_MOVE, ego = sim agent 0, nobody BLIND (the reference's env_args*.json and
 // BASELINE.md section 3) -- with those settings folded: no selects on them, no BLIND branch and
 // none of the register copies its join costs.  Anything else runs the general variant (XO = true).
-template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO>
-__global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
-                                                    int32_t *const comm_, int64_t *const metrics_,
-                                                    const int64_t n_, const int32_t block_,
-                                                    const MultiArgs p) {
-  // The six leading scalars repeat fields of `p` (and the workgroup size, which would
-  // otherwise come from the hidden arguments): as plain leading arguments they are preloaded
-  // into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, build.py), so the state
-  // and action loads are issued without first waiting for a scalar kernarg load.
-  // (block_ = workgroup size | which optional action sources are in use << 16: the branches on
-  // them are taken on a preloaded SGPR, not on a pointer that a scalar load has yet to deliver)
+//
+// DUTY: which of the step's OUTPUTS this wave produces.  Everything up to done/reward is needed by
+// every output and is computed by every wave; what follows splits four ways:
+//   DUTY_STATE  comm rows, done, sparse reward, the state rows, the metrics counters (and the
+//               in-place words of the optional random streams)
+//   DUTY_SHAPE  the reward shaping (distance lookups, fp64 sums), the shaped reward, episode statistics
+//   DUTY_OBS0 / DUTY_OBS1  get_observation2 for viewer 0 (+ the timestep) / viewer 1
+// DUTY_ALL is the whole step in one wave.  A *split* launch (k_multi_step<..., SP = 4>: four waves
+// per 64 envs in one workgroup, i.e. one wave on each SIMD of a CU) gives each wave one duty.  Why:
+// at the BASELINE batch sizes a step puts ONE wave on 64 ... 256 of the chip's 1 024 SIMDs, a lone
+// wave issues an instruction every ~7 cycles whatever the other SIMDs do, and the step lasts as
+// long as that wave's instruction stream (~950 instructions).  The stream is therefore cut where
+// the data flow forks, and the three idle SIMDs next door run the branches side by side: ~620
+// instructions per wave instead of ~950 (the part before the fork is recomputed by every wave --
+// free while the batch leaves SIMDs idle; each arm is compiled on its own, so the loads and the
+// arithmetic only another duty needs are gone from it).  The state is updated in place, so a split
+// workgroup passes one s_barrier between "every wave holds its copy of the state" and the first
+// store of anything a later-starting wave might still have to read.
+// Measured (tools/split_sweep.sh, MI355X): tomato-2, 4 096 envs 3.55 -> 3.07 us per step; equal at
+// 32 768 envs (every SIMD has a wave of its own by then), slower beyond: split_for().
+constexpr int DUTY_STATE = 1, DUTY_SHAPE = 2, DUTY_OBS0 = 4, DUTY_OBS1 = 8, DUTY_ALL = 15;
+
+template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int DUTY, bool SPLIT>
+__device__ __forceinline__ void multi_step_body(int32_t *const state_, const int32_t *const actions_,
+                                                int32_t *const comm_, int64_t *const metrics_,
+                                                const int64_t n_, const int32_t block_, const MultiArgs &p) {
   constexpr int A = 2;
+  constexpr bool D_STATE = (DUTY & DUTY_STATE) != 0, D_SHAPE = (DUTY & DUTY_SHAPE) != 0;
   using Out = RowsT<WT ? AUX_WT : 0>;
   OC_HDR_LOAD(p);
-  const int i = (int)blockIdx.x * (block_ & 0xFFFF) + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
+  // n < 2^31 / (4 * rows): fits_buffer().  Split: one workgroup = SP waves over the same 64 envs.
+  const int i = SPLIT ? (int)blockIdx.x * 64 + (int)(threadIdx.x & 63)
+                      : (int)blockIdx.x * (block_ & 0xFFFF) + (int)threadIdx.x;
   const bool valid = i < (int)n_;
   const bool ego_from_pairs = XO && ((block_ >> 16) & 1), alt_from_pairs = XO && ((block_ >> 17) & 1),
              alt_from_rng = XO && ((block_ >> 18) & 1), pairs64 = XO && ((block_ >> 19) & 1);
@@ -1589,15 +1607,18 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
       const Rows ac(actions_, n_, 4, i);
       ego_mv = ac.ld(0), ego_cm = ac.ld(1);
     }
+    uint32_t alt_rs = 0;
     if (alt_from_rng) {
-      uint32_t rs = (uint32_t)Rows(p.opt.alt_rng, n_, 1, i).ld(0);
-      alt_mv = (int)__umulhi(pcg32(rs), 4u);
-      alt_cm = (int)__umulhi(pcg32(rs), (uint32_t)p.cfg.obs.num_comm);
-      Rows(p.opt.alt_rng, n_, 1, i).st(0, (int)rs);
-      if (p.opt.alt_played != nullptr) {
-        const Rows ap(p.opt.alt_played, n_, 2, i);
-        ap.st(0, alt_mv);
-        ap.st(1, alt_cm);
+      alt_rs = (uint32_t)Rows(p.opt.alt_rng, n_, 1, i).ld(0);
+      alt_mv = (int)__umulhi(pcg32(alt_rs), 4u);
+      alt_cm = (int)__umulhi(pcg32(alt_rs), (uint32_t)p.cfg.obs.num_comm);
+      if constexpr (!SPLIT) {   // (split: stored behind the barrier, by the wave that owns the state)
+        Rows(p.opt.alt_rng, n_, 1, i).st(0, (int)alt_rs);
+        if (p.opt.alt_played != nullptr) {
+          const Rows ap(p.opt.alt_played, n_, 2, i);
+          ap.st(0, alt_mv);
+          ap.st(1, alt_cm);
+        }
       }
     } else if (alt_from_pairs && pairs64) {
       const Rows pr(p.opt.alt_pairs, n_, 1, i, 16);
@@ -1636,6 +1657,24 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     }
     Env<A, M, DUP> e;
     unpack<A, M, DUP>(e, w);
+    // split: nothing that is updated in place -- state rows, the words of the random streams, the
+    // done row the episode statistics read -- may be stored before every wave of the workgroup
+    // holds its copy
+    uint32_t place_rs = 0;
+    if constexpr (SPLIT) {
+      if (L.nscatter() != 0 && p.rng != nullptr) place_rs = (uint32_t)Rows(p.rng, n_, 1, i).ld(0);   // uniform
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr (D_STATE) {
+        if (alt_from_rng) {
+          Rows(p.opt.alt_rng, n_, 1, i).st(0, (int)alt_rs);
+          if (p.opt.alt_played != nullptr) {
+            const Rows ap(p.opt.alt_played, n_, 2, i);
+            ap.st(0, alt_mv);
+            ap.st(1, alt_cm);
+          }
+        }
+      }
+    }
     OC_STAMP(1);   // state + actions arrived
     // comm one-hots (:227-246); an index the reference's one_hot[idx] = 1 would raise on is
     // flagged (OC_ERR_ACTION) and sends nothing
@@ -1647,8 +1686,10 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     const bool bad_cm = (ego_talks && (unsigned)ego_cm >= NC) | (alt_talks && (unsigned)alt_cm >= NC);
     const int c0 = (ego_talks && (unsigned)ego_cm < NC) ? ego_cm : -1;
     const int c1 = (alt_talks && (unsigned)alt_cm < NC) ? alt_cm : -1;
-    cm.st(0, c0);
-    cm.st(1, c1);
+    if constexpr (D_STATE) {
+      cm.st(0, c0);
+      cm.st(1, c1);
+    }
     // NAV_ACTIONS lookup (both indices, moved or not: :248) + CAN_MOVE gating + ego_agent_idx
     // (:250-262); NAV_ACTIONS[idx] raises for idx > 3: flagged, executed as (0, 0)
     const bool bad_mv = ((unsigned)ego_mv > 3u) | ((unsigned)alt_mv > 3u);
@@ -1665,52 +1706,94 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     env_step<A, M, DUP, XO ? 2 : 0>(L, p.R, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
-    Out(p.done, p.n, 1, i).st(0, done);
+    if constexpr (D_STATE) {
+      Out(p.done, p.n, 1, i).st(0, done);
 #ifndef OC_STAMPS
-    if (p.sparse != nullptr) Out(p.sparse, p.n, 1, i).st(0, reward);
+      if (p.sparse != nullptr) Out(p.sparse, p.n, 1, i).st(0, reward);
 #endif
-    if (done && p.auto_reset) {
-#pragma unroll
-      for (int r = 0; r < WS; r++) w[r] = L.init_words(r);
-      place_items<A, M, WS>(L, tb, p.placement, p.rng, p.n, i, w);
-      unpack<A, M, DUP>(e, w);
-    } else {
-      pack<A, M, DUP>(e, w);
     }
+    if constexpr (DUTY != DUTY_SHAPE) {   // (the shaping reads the pre-reset env only, through `sin`)
+      if (done && p.auto_reset) {
 #pragma unroll
-    for (int r = 0; r < WS; r++) st.st(r, w[r]);
+        for (int r = 0; r < WS; r++) w[r] = L.init_words(r);
+        if constexpr (SPLIT) {   // every wave draws the same cells from its copy of the stream's word
+          place_items_from<A, M, WS>(L, tb, p.placement, p.rng != nullptr, place_rs, p.n, i, w);
+          if (D_STATE && L.nscatter() != 0 && p.rng != nullptr) p.rng[i] = place_rs;
+        } else {
+          place_items<A, M, WS>(L, tb, p.placement, p.rng, p.n, i, w);
+        }
+        unpack<A, M, DUP>(e, w);
+      } else {
+        pack<A, M, DUP>(e, w);
+      }
+    }
+    if constexpr (D_STATE) {
+#pragma unroll
+      for (int r = 0; r < WS; r++) st.st(r, w[r]);
+    }
     ShapeQ<2> sq;
-    shaping_lookup<2>(L, p.R.inv_max_path, sin, sld, sq OC_STAMP_PASS);
+    if constexpr (D_SHAPE) shaping_lookup<2>(L, p.R.inv_max_path, sin, sld, sq OC_STAMP_PASS);
     const int C = p.cfg.obs.num_comm;
     const int F = 22 + L.S() + 2 * C;
     const bool ego_blind = cfg_blind & 1;
     const Out ob(p.obs, p.n, 2 * F, i, OT == 1 ? 1 : 4);
-#pragma unroll
-    for (int v = 0; v < 2; v++)
-      env_obs<A, M, DUP, OT>(L, p.R, e, v, p.cfg.obs.fow_radius, (cfg_blind >> v) & 1, ego_blind, C, c0, c1, ob,
-                        v * F);
-    Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
+    if constexpr ((DUTY & DUTY_OBS0) != 0)
+      env_obs<A, M, DUP, OT>(L, p.R, e, 0, p.cfg.obs.fow_radius, cfg_blind & 1, ego_blind, C, c0, c1, ob, 0);
+    if constexpr ((DUTY & DUTY_OBS1) != 0)
+      env_obs<A, M, DUP, OT>(L, p.R, e, 1, p.cfg.obs.fow_radius, (cfg_blind >> 1) & 1, ego_blind, C, c0, c1, ob, F);
+    if constexpr ((DUTY & DUTY_OBS0) != 0) Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
     OC_STAMP(5);   // observation stores issued
-    // ... and they drain while the shaping is summed
-    double s0, s1;
-    shaping_sum<2>(L, sin, sq, s0, s1 OC_STAMP_PASS);
-    const double shaped = ((double)reward - s0) - s1;  // :282
-    Out(p.reward, p.n, 1, i, 8).st_f64(0, shaped);
-    if (XO && p.opt.ep_return != nullptr) {   // uniform
-      Out(p.opt.ep_return, p.n, 1, i, 8).st_f64(0, prev_done ? shaped : ep_ret + shaped);
-      Out(p.opt.ep_length, p.n, 1, i).st(0, prev_done ? 1 : ep_len + 1);
+    if constexpr (D_SHAPE) {
+      // ... and they drain while the shaping is summed
+      double s0, s1;
+      shaping_sum<2>(L, sin, sq, s0, s1 OC_STAMP_PASS);
+      const double shaped = ((double)reward - s0) - s1;  // :282
+      Out(p.reward, p.n, 1, i, 8).st_f64(0, shaped);
+      if (XO && p.opt.ep_return != nullptr) {   // uniform
+        Out(p.opt.ep_return, p.n, 1, i, 8).st_f64(0, prev_done ? shaped : ep_ret + shaped);
+        Out(p.opt.ep_length, p.n, 1, i).st(0, prev_done ? 1 : ep_len + 1);
+      }
     }
   }
   OC_STAMP(7);   // every store issued
-  slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
+  if constexpr (D_STATE) slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
   OC_STAMP(8);
 #ifdef OC_STAMPS
   // the sparse-reward pointer doubles as the debug buffer in this build: int64 [waves][16]
-  if ((threadIdx.x & 63) == 0 && p.sparse != nullptr) {
-    long long *dbg = (long long *)p.sparse + (i >> 6) * 16;
+  if ((threadIdx.x & 63) == 0 && p.sparse != nullptr) {   // one record per wave, split or not
+    long long *dbg = (long long *)p.sparse + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
     for (int k = 0; k < 16; k++) dbg[k] = (long long)oc_tt[k];
   }
 #endif
+}
+
+// OvercookedMultiEnv.multi_step in one launch.  SP = waves per 64 envs: 1 = one wave does the
+// whole step (block_ & 0xFFFF threads per workgroup); 4 = split launch, 256 threads per workgroup,
+// the wave's index picks its duty (a uniform branch; each arm is its own instruction stream).
+// The six leading scalars repeat fields of `p` (and the workgroup size, which would otherwise come
+// from the hidden arguments): as plain leading arguments they are preloaded into SGPRs at wave
+// launch (-mllvm -amdgpu-kernarg-preload-count, build.py), so the state and action loads are
+// issued without first waiting for a scalar kernarg load.  (block_ = workgroup size | which
+// optional action sources are in use << 16: the branches on them are taken on a preloaded SGPR,
+// not on a pointer that a scalar load has yet to deliver)
+template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int SP>
+__global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
+                                                    int32_t *const comm_, int64_t *const metrics_,
+                                                    const int64_t n_, const int32_t block_,
+                                                    const MultiArgs p) {
+  static_assert(SP == 1 || SP == 4, "waves per 64 envs");
+  static_assert(SP == 1 || !LDS, "the split launch reads the tables from global memory");
+#define OC_BODY(duty) multi_step_body<M, LDS, OT, WT, DUP, XO, (duty), true>(state_, actions_, comm_, metrics_, n_, block_, p)
+  if constexpr (SP == 1) {
+    multi_step_body<M, LDS, OT, WT, DUP, XO, DUTY_ALL, false>(state_, actions_, comm_, metrics_, n_, block_, p);
+  } else {
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (role == 0) OC_BODY(DUTY_STATE);
+    else if (role == 1) OC_BODY(DUTY_SHAPE);
+    else if (role == 2) OC_BODY(DUTY_OBS0);
+    else OC_BODY(DUTY_OBS1);
+  }
+#undef OC_BODY
 }
 
 // ---------------------------------------------------------------------------
@@ -1756,6 +1839,34 @@ int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_
                       (a.opt.pairs_int64 ? 8 : 0);
   return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.comm, a.metrics, a.n,
                   (int32_t)(block_size_for(n) | (src << 16)), a);
+}
+
+// Split launch of the fused step (k_multi_step<..., SP = 4>): 256 threads per workgroup over
+// ceil(n / 64) workgroups.
+template <typename K>
+int launch_ms_split(K kernel, int sp, const MultiArgs &a, int64_t n, void *stream) {
+  const int64_t grid = (n + 63) / 64;
+  if (grid > 0x7FFFFFFF) return fail(OC_E_BADARG, "n too large");
+  const int32_t src = (a.opt.ego_pairs ? 1 : 0) | (a.opt.alt_pairs ? 2 : 0) | (a.opt.alt_rng ? 4 : 0) |
+                      (a.opt.pairs_int64 ? 8 : 0);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * sp), 0, (hipStream_t)stream, a.state, a.actions,
+                     a.comm, a.metrics, a.n, (int32_t)(64 | (src << 16)), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "kernel launch");
+  return OC_OK;
+}
+
+// Waves per 64 envs for the fused step (see multi_step_body): four while that still leaves every
+// wave a SIMD of its own -- 4 * n / 64 <= 1 024 SIMDs (256 CUs x 4), i.e. n <= 16 384 on an MI355X.
+// tools/split_sweep.sh, tomato-2, us per step, one wave / four waves per 64 envs:
+//   n = 64 3.26 / 2.97, 1 024 3.55 / 3.03, 4 096 3.55 / 3.07, 8 192 3.74 / 3.10, 16 384 3.83 / 3.24,
+//   32 768 4.01 / 3.99, 65 536 5.35 / 5.50, 131 072 7.99 / 12.3.
+// The caller's hint (oc_step_opts.waves_per_64 = 1 / 4) and OC_SPLIT=1/4 (tuning) override.
+int split_for(int64_t n, int hint) {
+  static const int forced = getenv("OC_SPLIT") ? atoi(getenv("OC_SPLIT")) : 0;
+  if (forced == 1 || forced == 4) return forced;
+  if (hint == 1 || hint == 4) return hint;
+  return n <= 16384 ? 4 : 1;
 }
 
 bool write_through(int64_t n) {
@@ -2338,20 +2449,34 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   const bool std_cfg = cfg->communication_on && !cfg->ego_led && cfg->can_move_mask == 3 &&
                        cfg->ego_agent_idx == 0 && cfg->obs.blind_mask == 0 && !lv->run.play;
   const bool xo = o.ep_return || o.ego_pairs || o.alt_pairs || o.alt_rng || !std_cfg;
+  const int sp = oc_multi_step_waves(n, o.waves_per_64);   // split launch: write-through stores, tables in global memory
 #define OC_MS_X(MM, DD, XX)                                                           \
   do {                                                                                \
-    if (in_lds && ot == 0) return launch_ms(k_multi_step<MM, true, 0, false, DD, XX>, a, n, stream, lds);  \
-    if (ot == 1) return wt ? launch_ms(k_multi_step<MM, false, 1, true, DD, XX>, a, n, stream, 0)          \
-                           : launch_ms(k_multi_step<MM, false, 1, false, DD, XX>, a, n, stream, 0);        \
-    if (ot == 2) return wt ? launch_ms(k_multi_step<MM, false, 2, true, DD, XX>, a, n, stream, 0)          \
-                           : launch_ms(k_multi_step<MM, false, 2, false, DD, XX>, a, n, stream, 0);        \
-    return wt ? launch_ms(k_multi_step<MM, false, 0, true, DD, XX>, a, n, stream, 0)                       \
-              : launch_ms(k_multi_step<MM, false, 0, false, DD, XX>, a, n, stream, 0);                     \
+    if (in_lds && ot == 0) return launch_ms(k_multi_step<MM, true, 0, false, DD, XX, 1>, a, n, stream, lds);  \
+    if (ot == 1) return wt ? launch_ms(k_multi_step<MM, false, 1, true, DD, XX, 1>, a, n, stream, 0)          \
+                           : launch_ms(k_multi_step<MM, false, 1, false, DD, XX, 1>, a, n, stream, 0);        \
+    if (ot == 2) return wt ? launch_ms(k_multi_step<MM, false, 2, true, DD, XX, 1>, a, n, stream, 0)          \
+                           : launch_ms(k_multi_step<MM, false, 2, false, DD, XX, 1>, a, n, stream, 0);        \
+    return wt ? launch_ms(k_multi_step<MM, false, 0, true, DD, XX, 1>, a, n, stream, 0)                       \
+              : launch_ms(k_multi_step<MM, false, 0, false, DD, XX, 1>, a, n, stream, 0);                     \
   } while (0)
-#define OC_MS(MM, DD)            \
-  do {                           \
-    if (xo) OC_MS_X(MM, DD, true); \
-    OC_MS_X(MM, DD, false);      \
+#define OC_MS_SPLIT(MM, DD, XX)                                                                            \
+  do {                                                                                                     \
+    if (ot == 1) return launch_ms_split(k_multi_step<MM, false, 1, true, DD, XX, 4>, 4, a, n, stream);    \
+    if (ot == 2) return launch_ms_split(k_multi_step<MM, false, 2, true, DD, XX, 4>, 4, a, n, stream);    \
+    return launch_ms_split(k_multi_step<MM, false, 0, true, DD, XX, 4>, 4, a, n, stream);                 \
+  } while (0)
+#ifdef OC_SPECIALIZED
+#define OC_MS_SPLIT_XO(MM, DD) if (xo && sp == 4) OC_MS_SPLIT(MM, DD, true)
+#else
+#define OC_MS_SPLIT_XO(MM, DD)   // the generic library splits the plain variant only (its build time)
+#endif
+#define OC_MS(MM, DD)                            \
+  do {                                           \
+    OC_MS_SPLIT_XO(MM, DD);                      \
+    if (xo) OC_MS_X(MM, DD, true);               \
+    if (sp == 4) OC_MS_SPLIT(MM, DD, false);     \
+    OC_MS_X(MM, DD, false);                      \
   } while (0)
 #ifdef OC_SPECIALIZED
   OC_MS(OC_SPEC_HDR.M, OC_SPEC_DUP);
@@ -2368,7 +2493,13 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   return fail(OC_E_BADARG, "oc_multi_step: unsupported number of items");
 #endif
 #undef OC_MS
+#undef OC_MS_SPLIT_XO
+#undef OC_MS_SPLIT
 #undef OC_MS_X
+}
+
+int32_t oc_multi_step_waves(int64_t n, int32_t hint) {
+  return (write_through(n) && !tables_in_lds(n)) ? split_for(n, hint) : 1;
 }
 
 int oc_random_actions(uint32_t *rng, int32_t *move_row, int32_t *comm_row, int32_t num_comm, int64_t n,

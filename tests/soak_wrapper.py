@@ -49,7 +49,8 @@ def run(name, cfg, n, steps, seed, spec):
                             ego_config=cfg["ego"], partner_config=cfg["partner"], num_communication=C,
                             communication_on=cfg["comm_on"], ego_led=cfg["ego_led"],
                             fow_radius=cfg["radius"], ego_agent_idx=cfg["ego_idx"],
-                            obs_dtype=cfg["odt"], episode_stats=cfg["src"] != 0, **kw)
+                            obs_dtype=cfg["odt"], episode_stats=cfg["src"] != 0,
+                            waves_per_64=cfg.get("waves", 0), **kw)
     if lv.random_placement:
         env.set_placement(torch.from_numpy(place).cuda())
         env.reset()
@@ -104,6 +105,7 @@ def main():
                "odt": [torch.int32, torch.int32, torch.int8, torch.float32][int(crng.integers(0, 4))],
                "ego": {"ALLERGIC": flag(0.15), "BLIND": flag(0.15), "CAN_MOVE": not flag(0.1)},
                "partner": {"ALLERGIC": flag(0.15), "BLIND": flag(0.15), "CAN_MOVE": not flag(0.1)}}
+        cfg["waves"] = int(crng.choice([1, 4]))   # one wave per 64 envs / the split launch (same results)
         rsum, dones = run(name, cfg, n, steps, 500 + total % 97, use_spec)
         total += n * steps
         short = {k: (str(v).replace("torch.", "") if k == "odt" else v) for k, v in cfg.items()}

@@ -87,16 +87,18 @@ def _wrap_env(st, lv, n, **kw):
                 ego_agent_idx=st["ego_agent_idx"], **kw)
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "step+obs"])
+@pytest.mark.parametrize("fused", [4, 1, 0], ids=["fused-split", "fused-1wave", "step+obs"])
 @pytest.mark.parametrize("run", WRAP_RUNS, ids=[_rid(r) for r in WRAP_RUNS])
 def test_wrapper_matches_reference_golden(run, fused):
     """OvercookedMultiEnv.multi_step / multi_reset / get_observation2 tapes, through the
-    fused oc_multi_step kernel and through oc_step + oc_obs."""
+    fused oc_multi_step kernel -- as a split launch (four waves per 64 envs, one output each) and
+    with one wave computing the whole step -- and through oc_step + oc_obs."""
     path, spec = run
     z, st = load_golden(path)
     lv = compile_for(st)
     n = 70
-    env = _wrap_env(st, lv, n, auto_reset=False, specialize_level=spec, placement_mode="host")
+    env = _wrap_env(st, lv, n, auto_reset=False, specialize_level=spec, placement_mode="host",
+                    waves_per_64=fused)
     C = st["num_communication"]
     if lv.random_placement:
         env.set_placement(_placement_tensor(lv, z["placements"][0], n))
@@ -181,11 +183,12 @@ def test_step_matches_oracle_seeded(level, A, T, spec, oracle_lib):
     assert tot_d > 0 and tot_r > 0
 
 
+@pytest.mark.parametrize("waves", [4, 1], ids=["split", "1wave"])
 @pytest.mark.parametrize("spec", [False, True, "structure"], ids=["generic", "spec", "structure"])
 @pytest.mark.parametrize("level,T,C,radius", [("open-divider_tomato", 100, 2, 2),
                                               ("full-divider_salad", 120, 5, 1),
                                               ("open-divider_tl", 200, 3, 3)])
-def test_multi_step_matches_oracle_seeded(level, T, C, radius, spec, oracle_lib):
+def test_multi_step_matches_oracle_seeded(level, T, C, radius, spec, waves, oracle_lib):
     from gym_comm_amd import compiler
     lv = compiler.compile_level(level, 2, T)
     n, steps = 777, 200
@@ -195,8 +198,10 @@ def test_multi_step_matches_oracle_seeded(level, T, C, radius, spec, oracle_lib)
     acts = np.stack([mv[:, 0], cm[:, 0], mv[:, 1], cm[:, 1]], axis=1).astype(np.int32)
     ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
     comm = np.zeros((2, n), np.int32)
-    env = _env(lv, n, num_communication=C, fow_radius=radius, auto_reset=True, specialize_level=spec)
+    env = _env(lv, n, num_communication=C, fow_radius=radius, auto_reset=True, specialize_level=spec,
+               waves_per_64=waves)
     acts_d = torch.from_numpy(acts).cuda()
+    tot_d = 0
     for k in range(steps):
         o, t, r, d = env.multi_step(acts_d[k])
         oo, to, ro, do = ora.multi_step(acts[k], comm, radius, 0, C, auto_reset=True)
@@ -206,6 +211,11 @@ def test_multi_step_matches_oracle_seeded(level, T, C, radius, spec, oracle_lib)
         assert np.array_equal(o.cpu().numpy(), oo), ctx
         assert np.array_equal(bits(t.cpu().numpy()), bits(to)), ctx
         assert np.array_equal(env.comm.cpu().numpy(), comm), ctx
+        if k % 20 == 19:     # the state rows come from another wave than the observations in a split launch
+            assert_snapshots_equal(env.snapshot(), ora.snapshot_all(), ctx)
+        tot_d += int(do.sum())
+    m = env.read_metrics()
+    assert m["env_steps"] == n * steps and m["episodes"] == tot_d
 
 
 RANDOM_CASES = [("random-open-divider_salad_small", 2, 80), ("random-salad-superwide", 2, 100),
@@ -428,7 +438,7 @@ RNG_CASES = [("random-open-divider_salad_small", 40), ("random-salad-superwide",
 
 
 @pytest.mark.parametrize("spec", [False, True], ids=["generic", "spec"])
-@pytest.mark.parametrize("fused", [False, True], ids=["step", "fused"])
+@pytest.mark.parametrize("fused", [0, 4, 1], ids=["step", "fused-split", "fused-1wave"])
 @pytest.mark.parametrize("level,T", RNG_CASES, ids=[c[0] for c in RNG_CASES])
 def test_rng_placement_path_matches_oracle(level, T, fused, spec, oracle_lib):
     """placement_mode='rng' -- the production path of every random-* level the reference trains
@@ -443,7 +453,7 @@ def test_rng_placement_path_matches_oracle(level, T, fused, spec, oracle_lib):
     mv = scripted_then_random(rng, level, steps, 2, n, nact=4)
     cm = rng.integers(0, C, (steps, 2, n)).astype(np.int32)
     env = _env(lv, n, auto_reset=True, placement_mode="rng", seed=11, specialize_level=spec,
-               num_communication=C, fow_radius=radius)
+               num_communication=C, fow_radius=radius, waves_per_64=fused)
     assert env.kernel_flavour == ("spec" if spec else "generic")
     counters = {x | (y << 4) for x, y in lv.counters}
     ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
@@ -618,7 +628,8 @@ def test_dup_levels_match_oracle_seeded(name, A, spec, oracle_lib):
             assert np.array_equal(o.cpu().numpy(), oo), ctx
 
 
-def test_action_sources_agree(oracle_lib):
+@pytest.mark.parametrize("waves", [4, 1], ids=["split", "1wave"])
+def test_action_sources_agree(waves, oracle_lib):
     """oc_step_opts: the same (move, comm) actions as rows of `actions`, as int32 [n][2] pairs and
     as int64 [n][2] pairs give identical steps; an int64 value outside int32 is an invalid index
     (OC_ERR_ACTION); a partner drawn in-kernel (alt_rng) plays exactly what oc_random_actions
@@ -630,7 +641,7 @@ def test_action_sources_agree(oracle_lib):
     rng = np.random.default_rng(17)
     mv = rng.integers(0, 4, (steps, 2, n)).astype(np.int32)
     cm = rng.integers(0, C, (steps, 2, n)).astype(np.int32)
-    envs = [_env(lv, n, num_communication=C, fow_radius=1, auto_reset=True) for _ in range(4)]
+    envs = [_env(lv, n, num_communication=C, fow_radius=1, auto_reset=True, waves_per_64=waves) for _ in range(4)]
     seeds = torch.randint(0, 2 ** 31 - 1, (n,), dtype=torch.int64).to(torch.int32).cuda()
     r_kernel, r_lib = seeds.clone(), seeds.clone()
     played = torch.zeros((2, n), dtype=torch.int32, device="cuda")

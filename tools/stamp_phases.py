@@ -21,7 +21,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     env = BatchedOvercooked("open-divider_tomato", num_agents=2, num_envs=n, max_num_timesteps=500,
                             num_communication=2, auto_reset=True, specialize_level=True)
-    waves = (n + 63) // 64
+    sp = int(os.environ.get("OC_SPLIT", "1"))    # waves per 64 envs (split launch): one record per wave
+    waves = (n + 63) // 64 * sp
     dbg = torch.zeros((waves, 16), dtype=torch.int64, device="cuda")
     env.reward = dbg.view(torch.int32)          # the stamps build writes its stamps through `sparse`
     gen = torch.Generator(device="cuda").manual_seed(1)
@@ -33,15 +34,23 @@ def main():
         if k >= 100:
             rows.append(dbg.cpu().numpy().copy())
     t = np.stack(rows).astype(np.int64)          # [steps][waves][16]
-    d = np.diff(t[:, :, :9], axis=2)
-    med = np.median(d.reshape(-1, 8), axis=0)
-    tot = np.median(t[:, :, 8] - t[:, :, 0])
-    print("n = %d, %d waves; median shader cycles per phase (one wave):" % (n, waves))
-    for name, v in zip(NAMES, med):
-        print("  %-52s %8.0f  (%4.1f %%)" % (name, v, 100 * v / tot))
-    print("  %-52s %8.0f" % ("total (first stamp -> last stamp)", tot))
-    span = np.median(t[:, :, 8].max(axis=1) - t[:, :, 0].min(axis=1))
-    print("  first wave start -> last wave end: %.0f cycles" % span)
+    print("n = %d, %d waves (%d per 64 envs); median shader cycles per phase (one wave):" % (n, waves, sp))
+    for role in range(sp):
+        tr = t[:, role::sp, :9]
+        taken = [k for k in range(9) if (tr[:, :, k] != 0).all()]    # a wave only stamps the phases of its duties
+        if sp > 1:
+            print(" wave %d of the workgroup (stamps %s):" % (role, taken))
+        tot = np.median(tr[:, :, taken[-1]] - tr[:, :, taken[0]])
+        for a, b in zip(taken[:-1], taken[1:]):
+            v = np.median(tr[:, :, b] - tr[:, :, a])
+            name = NAMES[a] if b == a + 1 else "stamp %d -> %d" % (a, b)
+            print("  %-52s %8.0f  (%4.1f %%)" % (name, v, 100 * v / tot))
+        print("  %-52s %8.0f" % ("total (first stamp -> last stamp)", tot))
+    # (per workgroup: the stamps of different XCDs do not share an origin)
+    grp = t.reshape(t.shape[0], -1, sp, 16)[:, :, :, :9]
+    first = np.where(grp == 0, np.iinfo(np.int64).max, grp).min(axis=(2, 3))
+    span = np.median(grp.max(axis=(2, 3)) - first)
+    print("  first stamp -> last stamp of a workgroup: %.0f cycles" % span)
 
 
 if __name__ == "__main__":
