@@ -1263,19 +1263,20 @@ struct StepArgs {
 };
 
 // (leading scalars: preloaded kernel arguments, see k_multi_step)
-template <int A, int M, bool LDS, bool WT, bool DUP, bool PLAY>
-__global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32_t *const actions_,
-                                              int64_t *const metrics_, const int64_t n_, const int32_t launch_,
-                                              const int32_t T_, const void *const tables_,
-                                              const double inv_max_path_, const StepArgs p) {
-  // (tables_ / inv_max_path_ / T_ and, packed into launch_ = block | auto_reset << 16, the
-  // auto-reset flag too: this kernel runs at the SGPR limit with 3-4 agents, and the compiler
-  // otherwise loads each of them right before its first use and waits on the spot)
+// DUTY (see multi_step_body below): DUTY_STATE = reward, done, the state rows, metrics;
+// DUTY_SHAPE = the reward shaping of sim agents 0 and 1.  Both = the whole step in one wave.
+template <int A, int M, bool LDS, bool WT, bool DUP, bool PLAY, int DUTY, bool SPLIT>
+__device__ __forceinline__ void step_body(int32_t *const state_, const int32_t *const actions_,
+                                          int64_t *const metrics_, const int64_t n_, const int32_t launch_,
+                                          const int32_t T_, const void *const tables_,
+                                          const double inv_max_path_, const StepArgs &p) {
+  constexpr bool D_STATE = (DUTY & 1) != 0, D_SHAPE = (DUTY & 2) != 0;
   using Out = RowsT<WT ? AUX_WT : 0>;
   OC_HDR_LOAD(p);
   const int block_ = launch_ & 0xFFFF;
   const bool auto_reset_ = (launch_ >> 16) & 1;
-  const int i = (int)blockIdx.x * block_ + (int)threadIdx.x;   // n < 2^31 / (4 * rows): fits_buffer()
+  // n < 2^31 / (4 * rows): fits_buffer().  Split: one workgroup = two waves over the same 64 envs.
+  const int i = SPLIT ? (int)blockIdx.x * 64 + (int)(threadIdx.x & 63) : (int)blockIdx.x * block_ + (int)threadIdx.x;
   const bool valid = i < (int)n_;
   Tables tb;   // (global variant: formed after the state loads are issued, see k_multi_step)
   if constexpr (LDS) tb = stage_tables<true>(p.tables, p.n16, p.quot_bytes);
@@ -1295,6 +1296,8 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
     if constexpr (!LDS) tb = stage_tables<false>(tables_, p.n16, p.quot_bytes);
     Env<A, M, DUP> e;
     unpack<A, M, DUP>(e, w);
+    // split: no state row is stored before both waves hold their copy of the state
+    if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     const int err_before = e.err;
     constexpr int B = A < 2 ? A : 2;
     ShapeIn<B> sin;
@@ -1308,25 +1311,52 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
     comp = e.completed;
     err = e.err != err_before;
     ShapeQ<B> sq;
-    shaping_lookup<B>(L, inv_max_path_, sin, sld, sq OC_STAMP_PASS);
-    Out(p.reward, p.n, 1, i).st(0, reward);
-    Out(p.done, p.n, 1, i).st(0, done);
-    if (done && auto_reset_) {
+    if constexpr (D_SHAPE) shaping_lookup<B>(L, inv_max_path_, sin, sld, sq OC_STAMP_PASS);
+    if constexpr (D_STATE) {
+      Out(p.reward, p.n, 1, i).st(0, reward);
+      Out(p.done, p.n, 1, i).st(0, done);
+      if (done && auto_reset_) {
 #pragma unroll
-      for (int r = 0; r < WS; r++) w[r] = L.init_words(r);
-      place_items<A, M, WS>(L, tb, p.placement, p.rng, p.n, i, w);
-    } else {
-      pack<A, M, DUP>(e, w);
+        for (int r = 0; r < WS; r++) w[r] = L.init_words(r);
+        place_items<A, M, WS>(L, tb, p.placement, p.rng, p.n, i, w);
+      } else {
+        pack<A, M, DUP>(e, w);
+      }
+#pragma unroll
+      for (int r = 0; r < WS; r++) st.st(r, w[r]);
     }
-#pragma unroll
-    for (int r = 0; r < WS; r++) st.st(r, w[r]);
-    double s0, s1;
-    shaping_sum<B>(L, sin, sq, s0, s1 OC_STAMP_PASS);
-    const Out sh(p.shaping, p.n, 2, i, 8);
-    sh.st_f64(0, s0);
-    sh.st_f64(1, s1);
+    if constexpr (D_SHAPE) {
+      double s0, s1;
+      shaping_sum<B>(L, sin, sq, s0, s1 OC_STAMP_PASS);
+      const Out sh(p.shaping, p.n, 2, i, 8);
+      sh.st_f64(0, s0);
+      sh.st_f64(1, s1);
+    }
   }
-  slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
+  if constexpr (D_STATE) slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
+}
+
+// OvercookedEnvironment.step for n envs.  SP = waves per 64 envs: 1, or 2 = split launch (128
+// threads per workgroup: one wave steps and stores the state, the other computes the reward
+// shaping -- the same idea as k_multi_step's four-way split, see multi_step_body).
+template <int A, int M, bool LDS, bool WT, bool DUP, bool PLAY, int SP>
+__global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32_t *const actions_,
+                                              int64_t *const metrics_, const int64_t n_, const int32_t launch_,
+                                              const int32_t T_, const void *const tables_,
+                                              const double inv_max_path_, const StepArgs p) {
+  // (tables_ / inv_max_path_ / T_ and, packed into launch_ = block | auto_reset << 16, the
+  // auto-reset flag too: this kernel runs at the SGPR limit with 3-4 agents, and the compiler
+  // otherwise loads each of them right before its first use and waits on the spot)
+  static_assert(SP == 1 || (SP == 2 && !LDS), "waves per 64 envs");
+  if constexpr (SP == 1) {
+    step_body<A, M, LDS, WT, DUP, PLAY, 3, false>(state_, actions_, metrics_, n_, launch_, T_, tables_, inv_max_path_, p);
+  } else {
+    // (only launched by the specialised libraries, see oc_step)
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0)
+      step_body<A, M, LDS, WT, DUP, PLAY, 1, true>(state_, actions_, metrics_, n_, launch_, T_, tables_, inv_max_path_, p);
+    else
+      step_body<A, M, LDS, WT, DUP, PLAY, 2, true>(state_, actions_, metrics_, n_, launch_, T_, tables_, inv_max_path_, p);
+  }
 }
 
 struct ObsArgs {
@@ -1783,7 +1813,22 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
                                                     const MultiArgs p) {
   static_assert(SP == 1 || SP == 4, "waves per 64 envs");
   static_assert(SP == 1 || !LDS, "the split launch reads the tables from global memory");
-#define OC_BODY(duty) multi_step_body<M, LDS, OT, WT, DUP, XO, (duty), true>(state_, actions_, comm_, metrics_, n_, block_, p)
+#ifdef OC_SPECIALIZED
+  const MultiArgs &pk = p;
+#else
+  // Generic library: the split arms read the argument block through the kernarg segment pointer,
+  // not through the by-value parameter.  With the body inlined four times the compiler no longer
+  // forwarded `p` to the constant address space and kept a private copy instead -- 984 bytes of
+  // scratch per lane here, where the header accessors index into the block dynamically (17 us per
+  // step instead of 6.8; through the pointer 5.6).  The specialised libraries never had the copy
+  // (tests/test_host_cpu.py checks every kernel of every built library) and keep the parameter:
+  // loads through the pointer are not known to be invariant, and cost them 3 % (tomato-2) to 28 %
+  // (a random-* level, whose map geometry is read at run time).
+  struct KernArgs { int32_t *a; const int32_t *b; int32_t *c; int64_t *d; int64_t n; int32_t blk; MultiArgs p; };
+  [[maybe_unused]] const MultiArgs &pk = *reinterpret_cast<const MultiArgs *>(
+      reinterpret_cast<const char *>((const void *)__builtin_amdgcn_kernarg_segment_ptr()) + offsetof(KernArgs, p));
+#endif
+#define OC_BODY(duty) multi_step_body<M, LDS, OT, WT, DUP, XO, (duty), true>(state_, actions_, comm_, metrics_, n_, block_, pk)
   if constexpr (SP == 1) {
     multi_step_body<M, LDS, OT, WT, DUP, XO, DUTY_ALL, false>(state_, actions_, comm_, metrics_, n_, block_, p);
   } else {
@@ -1828,7 +1873,17 @@ int launch(K kernel, const Args &args, int64_t n, void *stream, size_t lds_bytes
 }
 // k_step / k_multi_step: hot scalars first (preloaded kernel arguments), then the full block
 template <typename K>
-int launch_st(K kernel, const StepArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
+int launch_st(K kernel, const StepArgs &a, int64_t n, void *stream, size_t lds_bytes = 0, int sp = 1) {
+  if (sp > 1) {   // split launch: sp waves per 64 envs, one workgroup each
+    const int64_t grid = (n + 63) / 64;
+    if (grid > 0x7FFFFFFF) return fail(OC_E_BADARG, "n too large");
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * sp), 0, (hipStream_t)stream, a.state, a.actions,
+                       a.metrics, a.n, (int32_t)(64 | ((a.auto_reset ? 1 : 0) << 16)), a.R.T, a.tables,
+                       a.R.inv_max_path, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return OC_OK;
+  }
   return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.metrics, a.n,
                   (int32_t)(block_size_for(n) | ((a.auto_reset ? 1 : 0) << 16)), a.R.T, a.tables,
                   a.R.inv_max_path, a);
@@ -1867,6 +1922,14 @@ int split_for(int64_t n, int hint) {
   if (forced == 1 || forced == 4) return forced;
   if (hint == 1 || hint == 4) return hint;
   return n <= 16384 ? 4 : 1;
+}
+
+// The same for the base step (k_step<..., SP = 2>: state wave + shaping wave).  OC_STEP_SPLIT=1/2
+// overrides; read at every call, so that tests can run both launches in one process.
+int step_split_for(int64_t n) {
+  const char *f = getenv("OC_STEP_SPLIT");
+  if (f && (f[0] == '1' || f[0] == '2') && !f[1]) return f[0] - '0';
+  return n <= 16384 ? 2 : 1;
 }
 
 bool write_through(int64_t n) {
@@ -2353,19 +2416,27 @@ int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_
   const bool pl = lv->run.play != 0;
   const size_t lds = (size_t)lv->n16 * 16;
   if (tables_in_lds(n)) {
-#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, true, false, DD, true>, a, n, stream, lds) \
-                                   : launch_st(k_step<AA, MM, true, false, DD, false>, a, n, stream, lds)
+#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, true, false, DD, true, 1>, a, n, stream, lds) \
+                                   : launch_st(k_step<AA, MM, true, false, DD, false, 1>, a, n, stream, lds)
     OC_FOR_AM(OC_X)
 #undef OC_X
   } else {
     if (write_through(n)) {
-#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, false, true, DD, true>, a, n, stream, 0) \
-                                   : launch_st(k_step<AA, MM, false, true, DD, false>, a, n, stream, 0)
+#ifdef OC_SPECIALIZED
+      if (step_split_for(n) == 2) {   // (specialised libraries only: the generic library's build time)
+#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, false, true, DD, true, 2>, a, n, stream, 0, 2) \
+                                   : launch_st(k_step<AA, MM, false, true, DD, false, 2>, a, n, stream, 0, 2)
+        OC_FOR_AM(OC_X)
+#undef OC_X
+      }
+#endif
+#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, false, true, DD, true, 1>, a, n, stream, 0) \
+                                   : launch_st(k_step<AA, MM, false, true, DD, false, 1>, a, n, stream, 0)
       OC_FOR_AM(OC_X)
 #undef OC_X
     }
-#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, false, false, DD, true>, a, n, stream, 0) \
-                                   : launch_st(k_step<AA, MM, false, false, DD, false>, a, n, stream, 0)
+#define OC_X(AA, MM, DD) return pl ? launch_st(k_step<AA, MM, false, false, DD, true, 1>, a, n, stream, 0) \
+                                   : launch_st(k_step<AA, MM, false, false, DD, false, 1>, a, n, stream, 0)
     OC_FOR_AM(OC_X)
 #undef OC_X
   }
@@ -2449,7 +2520,8 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   const bool std_cfg = cfg->communication_on && !cfg->ego_led && cfg->can_move_mask == 3 &&
                        cfg->ego_agent_idx == 0 && cfg->obs.blind_mask == 0 && !lv->run.play;
   const bool xo = o.ep_return || o.ego_pairs || o.alt_pairs || o.alt_rng || !std_cfg;
-  const int sp = oc_multi_step_waves(n, o.waves_per_64);   // split launch: write-through stores, tables in global memory
+  const int sp = oc_multi_step_waves(n, o.waves_per_64);
+  (void)sp;   // split launch: write-through stores, tables in global memory
 #define OC_MS_X(MM, DD, XX)                                                           \
   do {                                                                                \
     if (in_lds && ot == 0) return launch_ms(k_multi_step<MM, true, 0, false, DD, XX, 1>, a, n, stream, lds);  \
@@ -2466,16 +2538,18 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
     if (ot == 2) return launch_ms_split(k_multi_step<MM, false, 2, true, DD, XX, 4>, 4, a, n, stream);    \
     return launch_ms_split(k_multi_step<MM, false, 0, true, DD, XX, 4>, 4, a, n, stream);                 \
   } while (0)
+// (the generic library splits the plain variant only: its build time)
 #ifdef OC_SPECIALIZED
-#define OC_MS_SPLIT_XO(MM, DD) if (xo && sp == 4) OC_MS_SPLIT(MM, DD, true)
+#define OC_MS_SPLIT_BOTH(MM, DD)                   \
+  if (xo && sp == 4) OC_MS_SPLIT(MM, DD, true);    \
+  if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, false)
 #else
-#define OC_MS_SPLIT_XO(MM, DD)   // the generic library splits the plain variant only (its build time)
+#define OC_MS_SPLIT_BOTH(MM, DD) if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, false)
 #endif
 #define OC_MS(MM, DD)                            \
   do {                                           \
-    OC_MS_SPLIT_XO(MM, DD);                      \
+    OC_MS_SPLIT_BOTH(MM, DD);                    \
     if (xo) OC_MS_X(MM, DD, true);               \
-    if (sp == 4) OC_MS_SPLIT(MM, DD, false);     \
     OC_MS_X(MM, DD, false);                      \
   } while (0)
 #ifdef OC_SPECIALIZED
@@ -2493,7 +2567,7 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   return fail(OC_E_BADARG, "oc_multi_step: unsupported number of items");
 #endif
 #undef OC_MS
-#undef OC_MS_SPLIT_XO
+#undef OC_MS_SPLIT_BOTH
 #undef OC_MS_SPLIT
 #undef OC_MS_X
 }

@@ -148,12 +148,16 @@ def test_wrapper_matches_reference_golden(run, fused):
 CASES = SEEDED_CASES
 
 
-@pytest.mark.parametrize("spec", [False, True, "structure"], ids=["generic", "spec", "structure"])
+@pytest.mark.parametrize("spec,waves", [(False, 1), (True, 2), (True, 1), ("structure", 2)],
+                         ids=["generic", "spec-split", "spec-1wave", "structure-split"])
 @pytest.mark.parametrize("level,A,T", CASES, ids=["%s-a%d" % (c[0], c[1]) for c in CASES])
-def test_step_matches_oracle_seeded(level, A, T, spec, oracle_lib):
+def test_step_matches_oracle_seeded(level, A, T, spec, waves, oracle_lib, monkeypatch):
     """Seeded action streams, every env different, auto-reset on: full state compare with
-    the oracle after every step (ragged batch: 1000 envs = 15 waves + a 40-lane tail)."""
+    the oracle after every step (ragged batch: 1000 envs = 15 waves + a 40-lane tail).  The
+    specialised libraries launch the step split over two waves per 64 envs (state wave + shaping
+    wave) at this batch size; `1wave` forces the one-wave launch large batches get."""
     from gym_comm_amd import compiler
+    monkeypatch.setenv("OC_STEP_SPLIT", str(waves))
     lv = compiler.compile_level(level, A, T)
     n, steps = 1000, 260
     rng = np.random.default_rng(1234 + A)

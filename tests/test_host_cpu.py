@@ -104,6 +104,12 @@ def test_c_abi_exports_every_declared_symbol():
     bad = np.zeros(32, np.int32)
     h = ctypes.c_void_p()
     assert L.oc_level_create(bad.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 32, ctypes.byref(h)) == -1
+    # launch policy of the fused step (host only): four waves per 64 envs while each still gets a
+    # SIMD of its own (n <= 16384 on an MI355X), one beyond; the caller's hint overrides
+    if "OC_SPLIT" not in os.environ:
+        assert [L.oc_multi_step_waves(n, 0) for n in (1, 4096, 16384, 16385, 131072)] == [4, 4, 4, 1, 1]
+        assert L.oc_multi_step_waves(4096, 1) == 1 and L.oc_multi_step_waves(131072, 4) == 4
+        assert L.oc_multi_step_waves(4096, 7) == 4 and L.oc_multi_step_waves(131072, -3) == 1
 
 
 def test_product_fails_loudly_without_gpu():
@@ -336,6 +342,35 @@ def test_no_kernel_spills_to_scratch(tmp_path):
     assert re.search(r"k_multi_step.*?\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", text, re.S)
     pre = [int(v) for v in re.findall(r"\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", text)]
     assert max(pre) >= 10, pre
+
+
+def test_no_built_library_uses_scratch(tmp_path):
+    """Every kernel of every library build() produced -- the generic one and all specialised
+    level / structure libraries -- runs without a private segment (read from the code objects'
+    metadata).  A split launch of the generic fused step once kept a 984-byte private copy of its
+    argument block per lane (17 us per step instead of 6.8) and no test noticed."""
+    import glob
+    from gym_comm_amd import build, specialize
+    tools = "/opt/rocm/lib/llvm/bin/"
+    if not all(os.path.exists(tools + t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        pytest.skip("llvm binary tools not available")
+    libs = [os.path.join(build.CSRC, "liboc_hip.so")] + sorted(glob.glob(os.path.join(specialize.SPEC_DIR, "*.so")))
+    libs = [l for l in libs if os.path.exists(l)]
+    if not libs:
+        pytest.skip("nothing built")
+    kernels = 0
+    for k, so in enumerate(libs):
+        fat, co = str(tmp_path / ("f%d.bin" % k)), str(tmp_path / ("k%d.co" % k))
+        subprocess.run([tools + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, so], check=True)
+        subprocess.run([tools + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--" + build.ARCH, "--output=" + co], check=True)
+        notes = subprocess.run([tools + "llvm-readelf", "--notes", co], capture_output=True, text=True,
+                               check=True).stdout
+        sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+        assert sizes and max(sizes) == 0, (os.path.basename(so), max(sizes))
+        kernels += len(sizes)
+        os.remove(fat), os.remove(co)
+    assert kernels >= 20 * len(libs)
 
 
 def test_no_jit_compile_under_a_profiler(monkeypatch, tmp_path):
