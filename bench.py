@@ -28,8 +28,9 @@ clock over the whole region is reported beside it (``ms_per_step_wall``).
 
 ``--mode closed-loop`` measures the same kernel with policies in the loop (an ego and a
 partner MLP on the observations, actions sampled on the device, episode statistics; one
-hipGraph per step block) through ``OvercookedVecEnv``; it is reported with its own metric
-name, never instead of the headline.
+hipGraph per step block) through ``OvercookedVecEnv``; ``--policy fused`` (default) evaluates both
+MLPs in one launch of the hand-written MFMA kernel (include/oc_policy.h), ``--policy torch`` as
+torch modules; it is reported with its own metric name, never instead of the headline.
 
 Prints ONE JSON line (rank 0).
 """
@@ -105,6 +106,9 @@ def parse(argv=None):
     p.add_argument("--obs-dtype", default="int32", choices=sorted(ELEM),
                    help="observation rows: int32 (SURVEY 8(d) accounting), int8 (4x fewer bytes) or float32")
     p.add_argument("--hidden", type=int, default=64, help="closed-loop: width of the two policy MLPs")
+    p.add_argument("--policy", default="fused", choices=["fused", "torch"],
+                   help="closed-loop: the two MLP policies as ONE launch of the hand-written MFMA kernel "
+                        "(include/oc_policy.h) or as torch modules (~12 launches each)")
     p.add_argument("--waves-per-64", type=int, default=0, choices=[0, 1, 4],
                    help="launch hint of the fused step: 0 = the library decides (split launch up to 16384 envs), "
                         "1 = one wave per 64 envs, 4 = split launch (include/oc_hip.h, oc_step_opts)")
@@ -280,16 +284,21 @@ def main():
     G = max(1, min(args.graph_steps, WINDOW))
 
     if closed:
-        from gym_comm_amd.vec_env import OvercookedVecEnv, MLPPolicy, TorchPolicyPartner
+        from gym_comm_amd.vec_env import FusedMLPPartner, OvercookedVecEnv, MLPPolicy, TorchPolicyPartner
         arglist = dict(level=args.level, num_agents=2, max_num_timesteps=args.T,
                        num_communication=args.comm, communication_on=True, fow_radius=2)
-        partner = TorchPolicyPartner(MLPPolicy(3, args.comm, hidden=args.hidden, seed=seed + 1).to(dev),
-                                     sample=True, seed=seed + 2, device=dev)
-        venv = OvercookedVecEnv(arglist, n, partner=partner, device=dev, seed=seed,
-                                obs_dtype=torch.float32)
+        fused = args.policy == "fused"
+        if fused and (args.hidden != 64 or args.comm > 16):
+            raise SystemExit("--policy fused: 64 hidden units, at most 16 comm channels (use --policy torch)")
+        # fused: the hand-written MFMA policy kernel reads the int32 rows as they lie; torch: the
+        # module's first GEMM wants float32 rows
+        venv = OvercookedVecEnv(arglist, n, device=dev, seed=seed,
+                                obs_dtype=torch.int32 if fused else torch.float32)
         env = venv._b
-        ego = TorchPolicyPartner(MLPPolicy(env.S, args.comm, hidden=args.hidden, seed=seed + 3).to(dev),
-                                 sample=True, seed=seed + 4, device=dev)
+        seat = (lambda pol, sd: FusedMLPPartner(pol, sample=True, seed=sd, device=dev)) if fused else \
+               (lambda pol, sd: TorchPolicyPartner(pol, sample=True, seed=sd, device=dev))
+        venv.partner = seat(MLPPolicy(env.S, args.comm, hidden=args.hidden, seed=seed + 1).to(dev), seed + 2)
+        ego = seat(MLPPolicy(env.S, args.comm, hidden=args.hidden, seed=seed + 3).to(dev), seed + 4)
         with torch.cuda.stream(stream):
             venv.reset_tensors()
             loop = venv.closed_loop(ego, graph=False)  # ego fwd -> partner fwd -> step (+ stats in-kernel)
@@ -426,13 +435,15 @@ def main():
             "dtype": "int32" if closed else args.obs_dtype, "data": "synthetic",
             "config": {"workload": "%s, %d agents, %d parallel envs per GPU, T=%d, C=%d, %s"
                                    % (args.level, args.agents, n, args.T, args.comm,
-                                      ("closed loop: 2 MLP policies (hidden %d) + fused multi_step + "
-                                       "episode statistics" % args.hidden) if closed else
+                                      ("closed loop: 2 MLP policies (hidden %d, %s) + fused multi_step + "
+                                       "episode statistics" % (args.hidden, "one MFMA kernel launch for both"
+                                                               if args.policy == "fused" else "torch modules"))
+                                      if closed else
                                       "fused multi_step (step+obs)" if wrapper else "step only"),
                        "mode": args.mode,
                        "level": args.level, "num_agents": args.agents, "envs_per_gpu": n,
                        "max_num_timesteps": args.T, "launch": "hipgraph" if use_graph else "eager",
-                       "obs_dtype": "float32" if closed else args.obs_dtype,
+                       "obs_dtype": ("int32" if args.policy == "fused" else "float32") if closed else args.obs_dtype,
                        "kernel_flavour": env.kernel_flavour,
                        "waves_per_64_envs": env.launch_waves_per_64 if wrapper else 1,
                        "parallelism": "env-sharded x%d" % world},

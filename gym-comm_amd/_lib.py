@@ -36,6 +36,18 @@ class StepOpts(ctypes.Structure):
                 ("pairs_int64", ctypes.c_int32), ("waves_per_64", ctypes.c_int32)]
 
 
+POLICY_ABI_VERSION = 1   # include/oc_policy.h: OC_POLICY_ABI_VERSION
+POLICY_SYMBOLS = ["oc_policy_abi_version", "oc_policy_last_error", "oc_policy_ksteps", "oc_policy_pack_w1",
+                  "oc_policy_pack_w2", "oc_policy_pack_b2", "oc_policy_mlp"]
+
+
+class PolicyPlayer(ctypes.Structure):
+    """oc_policy_player (include/oc_policy.h)."""
+    _fields_ = [("obs", ctypes.c_void_p), ("w1", ctypes.c_void_p), ("w2", ctypes.c_void_p),
+                ("b2", ctypes.c_void_p), ("rng", ctypes.c_void_p), ("pairs", ctypes.c_void_p),
+                ("logits", ctypes.c_void_p)]
+
+
 class OcError(RuntimeError):
     pass
 
@@ -128,3 +140,33 @@ def subtask_info(blob, lib=None):
     check(L.oc_level_subtask_info(blob.ctypes.data_as(_I32P), int(blob.size), slot.ctypes.data_as(_I32P),
                                   gi.ctypes.data_as(_I32P), ctypes.byref(dup)), "oc_level_subtask_info", L)
     return slot.tolist(), gi.tolist(), bool(dup.value)
+
+
+def load_policy(path=None):
+    """Load (once) and type liboc_policy.so (include/oc_policy.h): the fused MLP policy kernel."""
+    path = os.path.abspath(path or os.environ.get("OC_POLICY_LIB") or _build.POLICY_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise OcError(
+            "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (there is no CPU fallback)" % path)
+    _preload_torch_hip_runtime()
+    L = ctypes.CDLL(path)
+    vp, fp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)
+    L.oc_policy_abi_version.restype = ctypes.c_int
+    L.oc_policy_last_error.restype = ctypes.c_char_p
+    L.oc_policy_ksteps.argtypes = [ctypes.c_int32]
+    L.oc_policy_ksteps.restype = ctypes.c_int32
+    L.oc_policy_pack_w1.argtypes = [fp, fp, fp, ctypes.c_int32, vp]
+    L.oc_policy_pack_w2.argtypes = [fp, ctypes.c_int32, vp]
+    L.oc_policy_pack_b2.argtypes = [fp, ctypes.c_int32, fp]
+    L.oc_policy_mlp.argtypes = [ctypes.POINTER(PolicyPlayer), ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_int32,
+                                ctypes.c_int32, ctypes.c_int64, vp]
+    for f in ("oc_policy_pack_w1", "oc_policy_pack_w2", "oc_policy_pack_b2", "oc_policy_mlp"):
+        getattr(L, f).restype = ctypes.c_int
+    if L.oc_policy_abi_version() != POLICY_ABI_VERSION:
+        raise OcError("liboc_policy.so ABI version mismatch")
+    L._oc_path = path
+    _libs[path] = L
+    return L

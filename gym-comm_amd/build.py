@@ -10,7 +10,14 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["oc_kernels.hip"]
+HEADERS = ["oc_hip.h", "oc_level.h"]          # include/: what SOURCES include
 LIB = os.path.join(CSRC, "liboc_hip.so")
+# the policy library (include/oc_policy.h): its own translation unit and shared object, so that
+# the stepper's specialised builds neither contain nor depend on it
+POLICY_SOURCES = ["oc_policy.hip"]
+POLICY_HEADERS = ["oc_policy.h"]
+POLICY_LIB = os.path.join(CSRC, "liboc_policy.so")
+POLICY_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
@@ -28,34 +35,46 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC=)")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB, sources=SOURCES, headers=HEADERS):
+    if not os.path.exists(lib):
         return True
-    deps = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = [os.path.join(CSRC, s) for s in sources]
     inc = os.path.join(CSRC, "..", "..", "include")
-    deps += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
-    return os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps)
+    deps += [os.path.join(inc, f) for f in headers]
+    return os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source into csrc/liboc_hip.so.  Returns the library path."""
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc_path(), "--offload-arch=" + ARCH] + FLAGS + list(extra_flags)
-    tmp = "%s.%d.tmp" % (LIB, os.getpid())        # concurrent builders never share a temporary
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+def _compile(lib, sources, flags, verbose):
+    cmd = [hipcc_path(), "--offload-arch=" + ARCH] + list(flags)
+    tmp = "%s.%d.tmp" % (lib, os.getpid())        # concurrent builders never share a temporary
+    cmd += [os.path.join(CSRC, s) for s in sources] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
     env = {k: v for k, v in os.environ.items()
            if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCTRACER", "HSA_TOOLS_LIB"))}
     try:
         subprocess.check_call(cmd, env=env)
-        os.replace(tmp, LIB)
+        os.replace(tmp, lib)
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
-    return LIB
+    return lib
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile the stepper into csrc/liboc_hip.so.  Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    return _compile(LIB, SOURCES, FLAGS + list(extra_flags), verbose)
+
+
+def build_policy(force=False, verbose=False):
+    """Compile the MLP policy kernel (include/oc_policy.h) into csrc/liboc_policy.so."""
+    if not force and not needs_build(POLICY_LIB, POLICY_SOURCES, POLICY_HEADERS):
+        return POLICY_LIB
+    return _compile(POLICY_LIB, POLICY_SOURCES, POLICY_FLAGS, verbose)
 
 
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_policy(force=True, verbose=True))

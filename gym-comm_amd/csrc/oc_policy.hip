@@ -1,0 +1,252 @@
+// oc_policy.hip -- liboc_policy.so: a 64-unit tanh MLP policy on the observation rows of the
+// batched Overcooked stepper, sampled into (move, comm) pairs (include/oc_policy.h).
+//
+// gfx950 only.  One wave = 32 envs.  Both products run on the matrix cores:
+//
+//   H^T [64 hidden x 32 envs] = W1aug [64 x K] . X^T [K x 32 envs]      v_mfma_f32_32x32x16_f16
+//       A = weights (fragment order, one 16-byte load per lane, M-tile and k-step),
+//       B = the observation: lane (env = l & 31, half h = l >> 5) holds features
+//           16 s + 8 h + 0..7 of ITS env -- eight coalesced row loads per k-step, converted to
+//           fp16 in registers; feature F is the timestep, F + 1 the constant 1 (bias b1).
+//   the accumulators hold H^T with the ENV ON THE LANE and the hidden units in the 16 registers
+//   (row = (r & 3) + 8 (r >> 2) + 4 h), which is exactly the B-operand layout of a product that
+//   sums over hidden units: registers 8 (s & 1) .. + 7 of M-tile s >> 1, tanh'ed and packed,
+//   are the B fragment of k-step s -- no LDS, no lane movement; the weights' k index is
+//   permuted on the host instead (oc_policy_pack_w2).
+//   L^T [32 rows x 32 envs] = W2row [32 x 64] . tanh(H^T)
+//       rows 0..3 = move logits -> registers 0..3 of the LOWER half-wave's lanes,
+//       comm logit c sits in row 4 + (c & 3) + 8 (c >> 2) -> register c of the UPPER half's
+//       lanes: lane l samples the move of env l & 31, lane l + 32 its comm -- each from its own
+//       PCG32 stream -- and the wave's 64 results are 256 contiguous bytes of the pairs tensor.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/oc_policy.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+int fail(const char *msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return -1;
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct Args {
+  oc_policy_player pl[2];
+  const double *timestep;
+  int32_t F, C, ksteps;
+  int64_t n;
+};
+
+__device__ __forceinline__ uint32_t pcg32(uint32_t &state) {   // the stepper's generator (oc_kernels.hip)
+  state = state * 747796405u + 2891336453u;
+  const uint32_t w = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+  return (w >> 22u) ^ w;
+}
+
+__device__ __forceinline__ float tanh_fast(float x) {
+  // 1 - 2 / (exp(2x) + 1); exp through v_exp_f32 (2^y).  |error| < 3e-7 on the fp32 result; the
+  // operands around it are fp16.  Saturates cleanly: exp -> inf gives 1, exp -> 0 gives -1.
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // 2 * log2(e)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+template <int OT>
+__device__ __forceinline__ float obs_at(const void *obs, int64_t idx) {
+  if (OT == 1) return (float)((const int8_t *)obs)[idx];
+  if (OT == 2) return ((const float *)obs)[idx];
+  return (float)((const int32_t *)obs)[idx];
+}
+
+// Gumbel-max over `count` candidates held in registers 0..count-1 of `v` (count <= 16):
+// argmax(logit - log(-log(u))), u uniform in (0, 1) from the lane's PCG32 stream; greedy when
+// `sample` is false.  Ties go to the lowest index (torch.argmax's rule on these sizes).
+__device__ __forceinline__ int pick(const f32x16 &v, int count, bool sample, uint32_t &state) {
+  float best = -3.0e38f;
+  int arg = 0;
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    if (c < count) {   // uniform per half-wave
+      float x = v[c];
+      if (sample) {
+        const float u = ((float)(pcg32(state) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        x -= __logf(-__logf(u));
+      }
+      const bool better = x > best;
+      best = better ? x : best;
+      arg = better ? c : arg;
+    }
+  }
+  return arg;
+}
+
+template <int OT>
+__global__ void __launch_bounds__(64) k_policy_mlp(const Args p) {
+  const oc_policy_player &P = p.pl[blockIdx.y];
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int64_t env0 = (int64_t)blockIdx.x * 32 + r;
+  const bool valid = env0 < p.n;
+  const int64_t env = valid ? env0 : p.n - 1;   // lanes past the batch compute on the last env, store nothing
+  const int F = p.F;
+  const float ts = (float)p.timestep[env];
+
+  // ---- H^T = W1aug . X^T ---------------------------------------------------------------
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int q = 0; q < 16; q++) acc0[q] = 0.0f, acc1[q] = 0.0f;
+  const half8 *w1 = (const half8 *)P.w1;
+  for (int s = 0; s < p.ksteps; s++) {
+    half8 b;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = 16 * s + 8 * h + j;
+      const int kr = k < F ? k : F - 1;                       // (always a readable row)
+      const float x = obs_at<OT>(P.obs, (int64_t)kr * p.n + env);
+      b[j] = (_Float16)(k < F ? x : k == F ? ts : k == F + 1 ? 1.0f : 0.0f);
+    }
+    const half8 a0 = w1[(size_t)(0 * p.ksteps + s) * 64 + lane];
+    const half8 a1 = w1[(size_t)(1 * p.ksteps + s) * 64 + lane];
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, acc1, 0, 0, 0);
+  }
+
+  // ---- L^T = W2row . tanh(H^T) + b2 ----------------------------------------------------
+  f32x16 out;
+  {
+    const float4 *b2 = (const float4 *)P.b2 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 v = b2[q];
+      out[4 * q + 0] = v.x, out[4 * q + 1] = v.y, out[4 * q + 2] = v.z, out[4 * q + 3] = v.w;
+    }
+  }
+  const half8 *w2 = (const half8 *)P.w2;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    half8 b;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float hv = (s >> 1) ? acc1[8 * (s & 1) + j] : acc0[8 * (s & 1) + j];
+      b[j] = (_Float16)tanh_fast(hv);
+    }
+    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s * 64 + lane], b, out, 0, 0, 0);
+  }
+
+  // ---- sample and store ------------------------------------------------------------------
+  // lower half-wave: move of env r from registers 0..3; upper: comm of env r from registers 0..C-1
+  const int count = h ? p.C : 4;
+  const bool sample = P.rng != nullptr;
+  uint32_t state = 0;
+  if (sample) state = P.rng[(int64_t)h * p.n + env];
+  const int choice = pick(out, count, sample, state);
+  if (valid) {
+    P.pairs[env * 2 + h] = choice;
+    if (sample) P.rng[(int64_t)h * p.n + env] = state;
+    if (P.logits != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 16; c++)
+        if (c < count) P.logits[(int64_t)((h ? 4 : 0) + c) * p.n + env] = out[c];
+    }
+  }
+}
+
+uint16_t f32_to_f16_bits(float f) {   // round to nearest even, host side
+  _Float16 hv = (_Float16)f;
+  uint16_t b;
+  memcpy(&b, &hv, 2);
+  return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oc_policy_abi_version(void) { return OC_POLICY_ABI_VERSION; }
+const char *oc_policy_last_error(void) { return g_err; }
+int32_t oc_policy_ksteps(int32_t F) { return (F + 2 + 15) / 16; }
+
+int oc_policy_pack_w1(const float *w1, const float *wt, const float *b1, int32_t F, uint16_t *out) {
+  if (!w1 || !wt || !b1 || !out || F < 1) return fail("oc_policy_pack_w1: bad argument");
+  const int ks = oc_policy_ksteps(F);
+  for (int m = 0; m < 2; m++)
+    for (int s = 0; s < ks; s++)
+      for (int l = 0; l < 64; l++)
+        for (int j = 0; j < 8; j++) {
+          const int row = 32 * m + (l & 31), k = 16 * s + 8 * (l >> 5) + j;
+          const float v = k < F ? w1[(size_t)row * F + k] : k == F ? wt[row] : k == F + 1 ? b1[row] : 0.0f;
+          out[(((size_t)m * ks + s) * 64 + l) * 8 + j] = f32_to_f16_bits(v);
+        }
+  return 0;
+}
+
+int oc_policy_pack_w2(const float *w2, int32_t C, uint16_t *out) {
+  if (!w2 || !out || C < 1 || C > OC_POLICY_MAX_COMM) return fail("oc_policy_pack_w2: bad argument (1 <= C <= 16)");
+  for (int s = 0; s < 4; s++)
+    for (int l = 0; l < 64; l++)
+      for (int j = 0; j < 8; j++) {
+        const int o = l & 31, hid = 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+        // which logit lives in row o: move o (o < 4), else comm c with o = 4 + (c & 3) + 8 (c >> 2)
+        int logit = -1;
+        if (o < 4) logit = o;
+        else if (((o - 4) & 7) < 4) {
+          const int c = ((o - 4) & 3) + 4 * ((o - 4) >> 3);
+          if (c < C) logit = 4 + c;
+        }
+        const float v = logit >= 0 ? w2[(size_t)logit * OC_POLICY_HIDDEN + hid] : 0.0f;
+        out[((size_t)s * 64 + l) * 8 + j] = f32_to_f16_bits(v);
+      }
+  return 0;
+}
+
+int oc_policy_pack_b2(const float *b2, int32_t C, float *out) {
+  if (!b2 || !out || C < 1 || C > OC_POLICY_MAX_COMM) return fail("oc_policy_pack_b2: bad argument (1 <= C <= 16)");
+  for (int l = 0; l < 64; l++)
+    for (int r = 0; r < 16; r++) {
+      const int o = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      int logit = -1;
+      if (o < 4) logit = o;
+      else if (((o - 4) & 7) < 4) {
+        const int c = ((o - 4) & 3) + 4 * ((o - 4) >> 3);
+        if (c < C) logit = 4 + c;
+      }
+      out[l * 16 + r] = logit >= 0 ? b2[logit] : 0.0f;
+    }
+  return 0;
+}
+
+int oc_policy_mlp(const oc_policy_player *players, int32_t num_players, const double *timestep, int32_t F,
+                  int32_t C, int32_t obs_type, int64_t n, void *stream) {
+  if (!players || num_players < 1 || num_players > 2 || !timestep || F < 1 || C < 1 || C > OC_POLICY_MAX_COMM ||
+      obs_type < 0 || obs_type > 2 || n < 0)
+    return fail("oc_policy_mlp: bad argument (1..2 players, 1 <= C <= 16, obs_type 0..2)");
+  if (n == 0) return 0;
+  Args a;
+  memset(&a, 0, sizeof(a));
+  for (int k = 0; k < num_players; k++) {
+    if (!players[k].obs || !players[k].w1 || !players[k].w2 || !players[k].b2 || !players[k].pairs)
+      return fail("oc_policy_mlp: a player needs obs, w1, w2, b2 and pairs");
+    a.pl[k] = players[k];
+  }
+  a.timestep = timestep;
+  a.F = F, a.C = C, a.ksteps = oc_policy_ksteps(F), a.n = n;
+  const int64_t grid = (n + 31) / 32;
+  if (grid > 0x7FFFFFFF) return fail("oc_policy_mlp: n too large");
+  const dim3 g((unsigned)grid, (unsigned)num_players), b(64);
+  if (obs_type == 1) hipLaunchKernelGGL(k_policy_mlp<1>, g, b, 0, (hipStream_t)stream, a);
+  else if (obs_type == 2) hipLaunchKernelGGL(k_policy_mlp<2>, g, b, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_policy_mlp<0>, g, b, 0, (hipStream_t)stream, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "oc_policy_mlp: kernel launch: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+}  // extern "C"

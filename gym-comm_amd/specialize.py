@@ -73,7 +73,7 @@ def _source_digest():
     h = hashlib.sha1()
     inc = os.path.join(_build.CSRC, "..", "..", "include")
     files = [os.path.join(_build.CSRC, s) for s in _build.SOURCES]
-    files += sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
+    files += [os.path.join(inc, f) for f in _build.HEADERS]      # what the source includes
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())

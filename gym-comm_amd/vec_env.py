@@ -36,6 +36,7 @@ Subclasses ``stable_baselines3.common.vec_env.VecEnv`` when SB3 is importable; o
 structural stand-in with the same methods.  ``step_tensors`` is the zero-copy variant for
 policies that live on the GPU.
 """
+import contextlib
 import ctypes
 import os
 
@@ -205,6 +206,115 @@ class TorchPolicyPartner:
             self.on_update(rewards, dones)
 
 
+class FusedMLPPartner:
+    """An ``MLPPolicy`` in the partner (or ego) seat as ONE launch of the hand-written policy
+    kernel (include/oc_policy.h, csrc/oc_policy.hip): both products on the matrix cores
+    (v_mfma_f32_32x32x16_f16, one wave = 32 envs, the hidden layer never leaves the accumulator
+    registers), tanh, Gumbel-max sampling from two PCG32 streams per env, and the result written as
+    the int32 [n][2] (move, comm) pairs the step kernel consumes as they lie.  What
+    ``TorchPolicyPartner(MLPPolicy(...))`` does in ~12 torch launches.  Two of them (ego + partner)
+    share one launch (``FusedMLPPartner.launch``).  Weights are packed once (``refresh()`` after an
+    optimiser step); fp16 operands, fp32 accumulation: logits within 2e-2 of the fp32 module's."""
+    graph_safe = True
+
+    def __init__(self, policy, sample=True, seed=0, device="cuda", keep_logits=False):
+        if not isinstance(policy, MLPPolicy):
+            raise TypeError("FusedMLPPartner runs gym_comm_amd.vec_env.MLPPolicy; wrap any other module "
+                            "in TorchPolicyPartner")
+        if policy.w1.shape[0] != 64:
+            raise ValueError("the fused kernel has 64 hidden units (got %d)" % policy.w1.shape[0])
+        if not 1 <= policy.C <= 16:
+            raise ValueError("the fused kernel samples at most 16 comm channels (got %d)" % policy.C)
+        self.policy, self.sample, self.seed = policy, bool(sample), int(seed)
+        self.device = torch.device(device)
+        self.keep_logits = bool(keep_logits)
+        self._L = _lib.load_policy()
+        self.F = int(policy.w1.shape[1])
+        self.C = int(policy.C)
+        self._w = None
+        self._rng = self.pairs = self.logits = None
+        self.refresh()
+
+    def refresh(self):
+        """(Re)pack the module's current weights into MFMA fragment order and upload them."""
+        L, pol = self._L, self.policy
+        f32 = lambda t: np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+        fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        ks = L.oc_policy_ksteps(self.F)
+        w1, wt, b1, w2, b2 = (f32(t) for t in (pol.w1, pol.wt, pol.b1, pol.w2, pol.b2))
+        o1 = np.zeros((2, ks, 64, 8), np.uint16)
+        o2 = np.zeros((4, 64, 8), np.uint16)
+        ob = np.zeros((64, 16), np.float32)
+        for rc, what in ((L.oc_policy_pack_w1(fp(w1), fp(wt.reshape(-1)), fp(b1.reshape(-1)), self.F,
+                                              o1.ctypes.data_as(ctypes.c_void_p)), "oc_policy_pack_w1"),
+                         (L.oc_policy_pack_w2(fp(w2), self.C, o2.ctypes.data_as(ctypes.c_void_p)), "oc_policy_pack_w2"),
+                         (L.oc_policy_pack_b2(fp(b2.reshape(-1)), self.C, fp(ob)), "oc_policy_pack_b2")):
+            if rc:
+                raise _lib.OcError("%s failed: %s" % (what, L.oc_policy_last_error().decode()))
+        dev = self.device
+        new = tuple(torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(dev) for a in (o1, o2, ob))
+        if self._w is None:
+            self._w = new
+        else:                       # in place: a captured graph keeps the addresses
+            for old, cur in zip(self._w, new):
+                old.copy_(cur)
+
+    def _buffers(self, n):
+        if self.pairs is None or self.pairs.shape[0] != n:
+            g = torch.Generator(device="cpu").manual_seed(self.seed)
+            self._rng = torch.randint(0, 2 ** 31 - 1, (2, n), generator=g, dtype=torch.int64
+                                      ).to(torch.int32).to(self.device)
+            self.pairs = torch.zeros((n, 2), dtype=torch.int32, device=self.device)
+            self.logits = (torch.zeros((4 + self.C, n), dtype=torch.float32, device=self.device)
+                           if self.keep_logits else None)
+
+    def _player(self, rows):
+        n = rows.shape[1]
+        if rows.shape[0] != self.F:
+            raise ValueError("the policy was built for %d observation rows, the env has %d" % (self.F, rows.shape[0]))
+        self._buffers(n)
+        return _lib.PolicyPlayer(rows.data_ptr(), self._w[0].data_ptr(), self._w[1].data_ptr(),
+                                 self._w[2].data_ptr(), self._rng.data_ptr() if self.sample else None,
+                                 self.pairs.data_ptr(), self.logits.data_ptr() if self.logits is not None else None)
+
+    @staticmethod
+    def launch(players, rows, timestep):
+        """One launch for one or two FusedMLPPartner, each on its own observation rows ([F][n]
+        views of the env's obs tensor); their ``pairs`` tensors hold the result."""
+        first = players[0]
+        if any(pl.F != first.F or pl.C != first.C for pl in players):
+            raise ValueError("players of one launch share F and C")
+        arr = (_lib.PolicyPlayer * len(players))(*[pl._player(r) for pl, r in zip(players, rows)])
+        ot = {torch.int32: 0, torch.int8: 1, torch.float32: 2}[rows[0].dtype]
+        dev = rows[0].device.index
+        n = rows[0].shape[1]
+        with (contextlib.nullcontext() if torch.cuda.current_device() == dev else torch.cuda.device(dev)):
+            rc = first._L.oc_policy_mlp(arr, len(players), timestep.data_ptr(), first.F, first.C, ot, n,
+                                        torch._C._cuda_getCurrentRawStream(dev))
+        if rc:
+            raise _lib.OcError("oc_policy_mlp failed (%d): %s" % (rc, first._L.oc_policy_last_error().decode()))
+
+    def pairs_for(self, obs):
+        """obs: an ``ObsView`` of the env (``rows`` [F][n], ``timestep``).  Returns int32 [n][2]."""
+        FusedMLPPartner.launch([self], [obs.rows], obs.timestep)
+        return self.pairs
+
+    def act_into(self, obs, move_row, comm_row):       # the generic partner protocol (two more copies)
+        pr = self.pairs_for(obs)
+        move_row.copy_(pr[:, 0])
+        comm_row.copy_(pr[:, 1])
+
+    def __call__(self, obs):
+        return self.pairs_for(obs)
+
+    def get_state(self, n):
+        self._buffers(n)
+        return self._rng.clone()
+
+    def set_state(self, st):
+        self._rng.copy_(st)
+
+
 class ClosedLoop:
     """ego policy -> partner policy -> fused step, ``steps`` times, as ONE hipGraph.
 
@@ -224,9 +334,19 @@ class ClosedLoop:
 
     def enqueue(self):
         v = self.venv
-        if self.ego is not None:
-            self.ego.act_into(v._obs_tensors(0), v._act[0], v._act[1])
-        v._partner_and_step(None)
+        ego, pt = self.ego, v.partner
+        if isinstance(ego, FusedMLPPartner):
+            if isinstance(pt, FusedMLPPartner) and pt.F == ego.F and pt.C == ego.C:
+                # both policies in ONE launch, their pairs consumed by the step as they lie
+                o0, o1 = v._obs_tensors(0), v._obs_tensors(1)
+                FusedMLPPartner.launch([ego, pt], [o0.rows, o1.rows], o0.timestep)
+                v._b.multi_step(v._act, ego_pairs=ego.pairs, alt_pairs=pt.pairs)
+            else:
+                v._partner_and_step(ego.pairs_for(v._obs_tensors(0)))
+        else:
+            if ego is not None:
+                ego.act_into(v._obs_tensors(0), v._act[0], v._act[1])
+            v._partner_and_step(None)
         v._version += 1
 
     def step(self):
@@ -385,7 +505,9 @@ class OvercookedVecEnv(_VecEnvBase):
             return
         partner_obs = self._obs_tensors(1)
         alt_pairs = None
-        if hasattr(pt, "act_into"):     # rows of the action tensor: ego move, ego comm, alt move, alt comm
+        if isinstance(pt, FusedMLPPartner):       # one launch; its pairs are consumed as they lie
+            alt_pairs = pt.pairs_for(partner_obs)
+        elif hasattr(pt, "act_into"):     # rows of the action tensor: ego move, ego comm, alt move, alt comm
             pt.act_into(partner_obs, self._act[2], self._act[3])
         else:
             pa = torch.as_tensor(pt(partner_obs), device=b.device)

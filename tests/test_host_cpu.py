@@ -112,6 +112,56 @@ def test_c_abi_exports_every_declared_symbol():
         assert L.oc_multi_step_waves(4096, 7) == 4 and L.oc_multi_step_waves(131072, -3) == 1
 
 
+def test_policy_library_exports_its_header_and_packs_fragments_as_documented():
+    """liboc_policy.so (include/oc_policy.h) loads without a GPU and exports what its header
+    declares; the host-side packers put every weight where the header says the MFMA fragments
+    expect it (an index-by-index restatement of the three layouts)."""
+    from gym_comm_amd import _lib, build
+    build.build_policy()
+    hdr = open(os.path.join(ROOT, "include", "oc_policy.h")).read()
+    declared = re.findall(r"OC_API\s+[\w\s\*]+?\b(oc_policy_\w+)\s*\(", hdr)
+    assert sorted(declared) == sorted(_lib.POLICY_SYMBOLS)
+    L = _lib.load_policy()
+    for sym in declared:
+        assert getattr(L, sym) is not None
+    assert L.oc_policy_abi_version() == _lib.POLICY_ABI_VERSION == 1
+    assert [L.oc_policy_ksteps(F) for F in (1, 14, 15, 29, 30, 31, 46, 47)] == [1, 1, 2, 2, 2, 3, 3, 4]
+    rng = np.random.default_rng(5)
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    f16 = lambda a: a.astype(np.float16).view(np.uint16)
+    for F, C in ((29, 2), (35, 5), (62, 16), (7, 1)):
+        ks = L.oc_policy_ksteps(F)
+        w1 = rng.standard_normal((64, F)).astype(np.float32)
+        wt, b1 = rng.standard_normal(64).astype(np.float32), rng.standard_normal(64).astype(np.float32)
+        w2 = rng.standard_normal((4 + C, 64)).astype(np.float32)
+        b2 = rng.standard_normal(4 + C).astype(np.float32)
+        o1, o2 = np.zeros((2, ks, 64, 8), np.uint16), np.zeros((4, 64, 8), np.uint16)
+        ob = np.zeros((64, 16), np.float32)
+        assert L.oc_policy_pack_w1(fp(w1), fp(wt), fp(b1), F, o1.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert L.oc_policy_pack_w2(fp(w2), C, o2.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert L.oc_policy_pack_b2(fp(b2), C, fp(ob)) == 0
+        aug = np.zeros((64, 16 * ks), np.float32)
+        aug[:, :F], aug[:, F], aug[:, F + 1] = w1, wt, b1
+        row_of = {o: o for o in range(4)}                       # logit -> row of the second product
+        row_of.update({4 + c: 4 + (c & 3) + 8 * (c >> 2) for c in range(C)})
+        w2row, b2row = np.zeros((32, 64), np.float32), np.zeros(32, np.float32)
+        for logit, o in row_of.items():
+            w2row[o], b2row[o] = w2[logit], b2[logit]
+        for l in range(64):
+            r, h = l & 31, l >> 5
+            for j in range(8):
+                for m in range(2):
+                    for s_ in range(ks):
+                        assert o1[m, s_, l, j] == f16(aug[32 * m + r, 16 * s_ + 8 * h + j])
+                for s_ in range(4):
+                    assert o2[s_, l, j] == f16(w2row[r, 16 * s_ + 8 * (j >> 2) + 4 * h + (j & 3)])
+            for reg in range(16):
+                assert ob[l, reg] == b2row[(reg & 3) + 8 * (reg >> 2) + 4 * h]
+    assert L.oc_policy_pack_w2(fp(np.zeros((21, 64), np.float32)), 17, o2.ctypes.data_as(ctypes.c_void_p)) != 0
+    assert b"C <= 16" in L.oc_policy_last_error()
+    assert L.oc_policy_mlp(None, 1, None, 29, 2, 0, 0, None) != 0      # argument errors before any launch
+
+
 def test_product_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

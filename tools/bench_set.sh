@@ -19,5 +19,7 @@ b rsmall --level random-open-divider_salad_small --no-cpu-baseline
 OC_SPECIALIZE=structure b structure_4096 --no-cpu-baseline
 OC_SPECIALIZE=0 b generic_4096 --no-cpu-baseline
 b closed_loop_4096 --mode closed-loop --no-cpu-baseline
+b closed_loop_torch_4096 --mode closed-loop --policy torch --no-cpu-baseline
 b closed_loop_131072 --mode closed-loop --envs 131072 --no-cpu-baseline
+b closed_loop_torch_131072 --mode closed-loop --policy torch --envs 131072 --no-cpu-baseline
 b gloo2_same_gpu --gpus 2 --same-gpu --backend gloo --no-cpu-baseline
