@@ -293,7 +293,7 @@ def main():
         # fused: the hand-written MFMA policy kernel reads the int32 rows as they lie; torch: the
         # module's first GEMM wants float32 rows
         venv = OvercookedVecEnv(arglist, n, device=dev, seed=seed,
-                                obs_dtype=torch.int32 if fused else torch.float32)
+                                obs_dtype=getattr(torch, args.obs_dtype) if fused else torch.float32)
         env = venv._b
         seat = (lambda pol, sd: FusedMLPPartner(pol, sample=True, seed=sd, device=dev)) if fused else \
                (lambda pol, sd: TorchPolicyPartner(pol, sample=True, seed=sd, device=dev))
@@ -432,7 +432,7 @@ def main():
             "ms_per_step": step_s * 1e3, "ms_per_step_wall": wall * 1e3 / (reps * K),
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32" if closed else args.obs_dtype, "data": "synthetic",
+            "dtype": args.obs_dtype if (not closed or args.policy == "fused") else "int32", "data": "synthetic",
             "config": {"workload": "%s, %d agents, %d parallel envs per GPU, T=%d, C=%d, %s"
                                    % (args.level, args.agents, n, args.T, args.comm,
                                       ("closed loop: 2 MLP policies (hidden %d, %s) + fused multi_step + "
@@ -443,7 +443,7 @@ def main():
                        "mode": args.mode,
                        "level": args.level, "num_agents": args.agents, "envs_per_gpu": n,
                        "max_num_timesteps": args.T, "launch": "hipgraph" if use_graph else "eager",
-                       "obs_dtype": ("int32" if args.policy == "fused" else "float32") if closed else args.obs_dtype,
+                       "obs_dtype": (args.obs_dtype if args.policy == "fused" else "float32") if closed else args.obs_dtype,
                        "kernel_flavour": env.kernel_flavour,
                        "waves_per_64_envs": env.launch_waves_per_64 if wrapper else 1,
                        "parallelism": "env-sharded x%d" % world},
