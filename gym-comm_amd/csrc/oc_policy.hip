@@ -1,7 +1,7 @@
 // oc_policy.hip -- liboc_policy.so: a 64-unit tanh MLP policy on the observation rows of the
 // batched Overcooked stepper, sampled into (move, comm) pairs (include/oc_policy.h).
 //
-// gfx950 only.  One wave = 32 envs.  Both products run on the matrix cores:
+// gfx950 only.  One wave = 32 envs (two waves per workgroup).  Both products run on the matrix cores:
 //
 //   H^T [64 hidden x 32 envs] = W1aug [64 x K] . X^T [K x 32 envs]      v_mfma_f32_32x32x16_f16
 //       A = weights (fragment order, one 16-byte load per lane, M-tile and k-step),
@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/oc_policy.h"
@@ -86,11 +87,20 @@ __device__ __forceinline__ int pick(const f32x16 &v, int count, bool sample, uin
   return arg;
 }
 
-template <int OT>
-__global__ void __launch_bounds__(64) k_policy_mlp(const Args p) {
-  const oc_policy_player &P = p.pl[blockIdx.y];
-  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-  const int64_t env0 = (int64_t)blockIdx.x * 32 + r;
+// Workgroup -> envs, XCD-aware.  WPB = 2 (the shipped mapping): a workgroup is 64 envs, workgroup x
+// of a player = envs 64 x .. 64 x + 63 -- the step kernels' mapping -- and the grid is one-
+// dimensional with every player's range padded to a multiple of 8 workgroups (`gx8`), so that
+// workgroup x of EVERY player runs on XCD x % 8 (workgroups are dealt to the 8 XCDs round-robin):
+// the observation rows a workgroup reads were written, a launch earlier, through the L2 of its
+// own XCD.  With 32-env workgroups in launch order (WPB = 1, kept for the A/B) a closed-loop step
+// cost more than its two kernels apart: 28.5 us against 21.3 at 131 072 envs; matched: 22.2.
+template <int OT, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_policy_mlp(const Args p, const int gx, const int gx8) {
+  const int x = (int)(blockIdx.x % (unsigned)gx8), y = (int)(blockIdx.x / (unsigned)gx8);
+  if (x >= gx) return;                       // padding workgroup (uniform)
+  const oc_policy_player &P = p.pl[y];
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int64_t env0 = ((int64_t)x * WPB + (threadIdx.x >> 6)) * 32 + r;
   const bool valid = env0 < p.n;
   const int64_t env = valid ? env0 : p.n - 1;   // lanes past the batch compute on the last env, store nothing
   const int F = p.F;
@@ -107,8 +117,8 @@ __global__ void __launch_bounds__(64) k_policy_mlp(const Args p) {
     for (int j = 0; j < 8; j++) {
       const int k = 16 * s + 8 * h + j;
       const int kr = k < F ? k : F - 1;                       // (always a readable row)
-      const float x = obs_at<OT>(P.obs, (int64_t)kr * p.n + env);
-      b[j] = (_Float16)(k < F ? x : k == F ? ts : k == F + 1 ? 1.0f : 0.0f);
+      const float xv = obs_at<OT>(P.obs, (int64_t)kr * p.n + env);
+      b[j] = (_Float16)(k < F ? xv : k == F ? ts : k == F + 1 ? 1.0f : 0.0f);
     }
     const half8 a0 = w1[(size_t)(0 * p.ksteps + s) * 64 + lane];
     const half8 a1 = w1[(size_t)(1 * p.ksteps + s) * 64 + lane];
@@ -235,12 +245,20 @@ int oc_policy_mlp(const oc_policy_player *players, int32_t num_players, const do
   }
   a.timestep = timestep;
   a.F = F, a.C = C, a.ksteps = oc_policy_ksteps(F), a.n = n;
-  const int64_t grid = (n + 31) / 32;
-  if (grid > 0x7FFFFFFF) return fail("oc_policy_mlp: n too large");
-  const dim3 g((unsigned)grid, (unsigned)num_players), b(64);
-  if (obs_type == 1) hipLaunchKernelGGL(k_policy_mlp<1>, g, b, 0, (hipStream_t)stream, a);
-  else if (obs_type == 2) hipLaunchKernelGGL(k_policy_mlp<2>, g, b, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_policy_mlp<0>, g, b, 0, (hipStream_t)stream, a);
+  const char *ev = getenv("OC_POLICY_WG32");   // tuning / A-B: 32-env workgroups in launch order
+  const int wpb = (ev && ev[0] == '1') ? 1 : 2;
+  const int64_t gx = (n + 32 * wpb - 1) / (32 * wpb), gx8 = (gx + 7) / 8 * 8;
+  if (gx8 * num_players > 0x7FFFFFFF) return fail("oc_policy_mlp: n too large");
+  const dim3 g((unsigned)(gx8 * num_players)), b(64 * wpb);
+#define OC_PL(OT_)                                                                                          \
+  do {                                                                                                      \
+    if (wpb == 2) hipLaunchKernelGGL((k_policy_mlp<OT_, 2>), g, b, 0, (hipStream_t)stream, a, (int)gx, (int)gx8); \
+    else hipLaunchKernelGGL((k_policy_mlp<OT_, 1>), g, b, 0, (hipStream_t)stream, a, (int)gx, (int)gx8);    \
+  } while (0)
+  if (obs_type == 1) OC_PL(1);
+  else if (obs_type == 2) OC_PL(2);
+  else OC_PL(0);
+#undef OC_PL
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "oc_policy_mlp: kernel launch: %s", hipGetErrorString(e));
