@@ -160,7 +160,7 @@ def load_policy(path=None):
     L.oc_policy_ksteps.restype = ctypes.c_int32
     L.oc_policy_pack_w1.argtypes = [fp, fp, fp, ctypes.c_int32, vp]
     L.oc_policy_pack_w2.argtypes = [fp, ctypes.c_int32, vp]
-    L.oc_policy_pack_b2.argtypes = [fp, ctypes.c_int32, fp]
+    L.oc_policy_pack_b2.argtypes = [fp, fp, ctypes.c_int32, fp]
     L.oc_policy_mlp.argtypes = [ctypes.POINTER(PolicyPlayer), ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_int32,
                                 ctypes.c_int32, ctypes.c_int64, vp]
     for f in ("oc_policy_pack_w1", "oc_policy_pack_w2", "oc_policy_pack_b2", "oc_policy_mlp"):

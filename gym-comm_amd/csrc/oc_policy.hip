@@ -51,38 +51,62 @@ __device__ __forceinline__ uint32_t pcg32(uint32_t &state) {   // the stepper's 
   return (w >> 22u) ^ w;
 }
 
-__device__ __forceinline__ float tanh_fast(float x) {
-  // 1 - 2 / (exp(2x) + 1); exp through v_exp_f32 (2^y).  |error| < 3e-7 on the fp32 result; the
-  // operands around it are fp16.  Saturates cleanly: exp -> inf gives 1, exp -> 0 gives -1.
-  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // 2 * log2(e)
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+// The activations are folded into the weights on the host (oc_policy_pack_*): with W1, wt, b1
+// scaled by 2 log2(e) the first product delivers a = 2 log2(e) h, and
+//     tanh(h) = 1 - 2 r,   r = 1 / (2^a + 1)                      (v_exp_f32, v_add, v_rcp_f32)
+// so the second product takes r itself with W2' = -2 log2(e) W2 and the accumulator started at
+// b2' = log2(e) (b2 + sum_j W2[.][j]): it delivers the logits in BASE 2 (logit * log2(e)), which
+// is what the sampler's 2^x wants.  Saturates cleanly: 2^a -> inf gives r = 0 (tanh 1), 2^a -> 0
+// gives r = 1 (tanh -1).
+constexpr float K_LOG2E = 1.4426950408889634f, K_LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float sigmoid_complement(float a) {
+  return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a) + 1.0f);
 }
 
+// element `idx` of the rows (32-bit unsigned index: scalar base + 32-bit vector offset addressing;
+// oc_policy_mlp checks F * n < 2^31)
 template <int OT>
-__device__ __forceinline__ float obs_at(const void *obs, int64_t idx) {
+__device__ __forceinline__ float obs_at(const void *obs, uint32_t idx) {
   if (OT == 1) return (float)((const int8_t *)obs)[idx];
   if (OT == 2) return ((const float *)obs)[idx];
   return (float)((const int32_t *)obs)[idx];
 }
 
-// Gumbel-max over `count` candidates held in registers 0..count-1 of `v` (count <= 16):
-// argmax(logit - log(-log(u))), u uniform in (0, 1) from the lane's PCG32 stream; greedy when
-// `sample` is false.  Ties go to the lowest index (torch.argmax's rule on these sizes).
+// One action out of `count` candidates whose base-2 logits sit in registers 0..count-1 of `v`
+// (count <= 16, uniform per half-wave).  Sampling: inverse CDF of the softmax with ONE uniform
+// draw from the lane's PCG32 stream -- p_c = 2^(l_c - max) / S, the action is the number of
+// cumulative sums that do not exceed u S.  Greedy (`sample` false): the first maximum
+// (torch.argmax's rule on these sizes).
+// `count` differs between the two half-waves (4 moves below, C comms above): candidates past a
+// lane's count are given the logit -inf (probability 0, never the maximum) instead of a branch;
+// CMAX (4, 8 or 16 >= max(4, C)) bounds the unrolled loops at compile time.
+template <int CMAX>
 __device__ __forceinline__ int pick(const f32x16 &v, int count, bool sample, uint32_t &state) {
-  float best = -3.0e38f;
-  int arg = 0;
+  float x[CMAX], m = -3.0e38f;
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
-    if (c < count) {   // uniform per half-wave
-      float x = v[c];
-      if (sample) {
-        const float u = ((float)(pcg32(state) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        x -= __logf(-__logf(u));
-      }
-      const bool better = x > best;
-      best = better ? x : best;
-      arg = better ? c : arg;
+  for (int c = 0; c < CMAX; c++) {
+    x[c] = c < count ? v[c] : -3.0e38f;
+    m = fmaxf(m, x[c]);
+  }
+  int arg = 0;
+  if (sample) {   // uniform
+    float total = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; c++) {
+      x[c] = __builtin_amdgcn_exp2f(x[c] - m);   // 2^-huge = 0 for the padding candidates
+      total += x[c];
     }
+    const float u = ((float)(pcg32(state) >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+    const float t = u * total;
+    float cum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX - 1; c++) {
+      cum += x[c];
+      arg += (cum <= t && c < count - 1) ? 1 : 0;
+    }
+  } else {
+#pragma unroll
+    for (int c = CMAX - 1; c >= 0; c--) arg = (x[c] == m) ? c : arg;   // the first maximum wins
   }
   return arg;
 }
@@ -94,7 +118,7 @@ __device__ __forceinline__ int pick(const f32x16 &v, int count, bool sample, uin
 // the observation rows a workgroup reads were written, a launch earlier, through the L2 of its
 // own XCD.  With 32-env workgroups in launch order (WPB = 1, kept for the A/B) a closed-loop step
 // cost more than its two kernels apart: 28.5 us against 21.3 at 131 072 envs; matched: 22.2.
-template <int OT, int WPB>
+template <int OT, int WPB, int CMAX>
 __global__ void __launch_bounds__(64 * WPB) k_policy_mlp(const Args p, const int gx, const int gx8) {
   const int x = (int)(blockIdx.x % (unsigned)gx8), y = (int)(blockIdx.x / (unsigned)gx8);
   if (x >= gx) return;                       // padding workgroup (uniform)
@@ -111,14 +135,20 @@ __global__ void __launch_bounds__(64 * WPB) k_policy_mlp(const Args p, const int
 #pragma unroll
   for (int q = 0; q < 16; q++) acc0[q] = 0.0f, acc1[q] = 0.0f;
   const half8 *w1 = (const half8 *)P.w1;
+  const uint32_t n32 = (uint32_t)p.n, e32 = (uint32_t)env;
   for (int s = 0; s < p.ksteps; s++) {
     half8 b;
+    const uint32_t k0 = 16 * s + 8 * h, off0 = k0 * n32 + e32;   // this lane's first feature of the k-step
+    if (16 * s + 16 <= F) {   // uniform: every feature of this k-step is an observation row
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int k = 16 * s + 8 * h + j;
-      const int kr = k < F ? k : F - 1;                       // (always a readable row)
-      const float xv = obs_at<OT>(P.obs, (int64_t)kr * p.n + env);
-      b[j] = (_Float16)(k < F ? xv : k == F ? ts : k == F + 1 ? 1.0f : 0.0f);
+      for (int j = 0; j < 8; j++) b[j] = (_Float16)obs_at<OT>(P.obs, off0 + (uint32_t)j * n32);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int k = (int)k0 + j;
+        const float xv = obs_at<OT>(P.obs, k < F ? off0 + (uint32_t)j * n32 : e32);   // (always a readable element)
+        b[j] = (_Float16)(k < F ? xv : k == F ? ts : k == F + 1 ? 1.0f : 0.0f);
+      }
     }
     const half8 a0 = w1[(size_t)(0 * p.ksteps + s) * 64 + lane];
     const half8 a1 = w1[(size_t)(1 * p.ksteps + s) * 64 + lane];
@@ -126,7 +156,7 @@ __global__ void __launch_bounds__(64 * WPB) k_policy_mlp(const Args p, const int
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, acc1, 0, 0, 0);
   }
 
-  // ---- L^T = W2row . tanh(H^T) + b2 ----------------------------------------------------
+  // ---- log2(e) L^T = W2' . r + b2'  (see sigmoid_complement) -----------------------------
   f32x16 out;
   {
     const float4 *b2 = (const float4 *)P.b2 + lane * 4;
@@ -142,8 +172,8 @@ __global__ void __launch_bounds__(64 * WPB) k_policy_mlp(const Args p, const int
     half8 b;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const float hv = (s >> 1) ? acc1[8 * (s & 1) + j] : acc0[8 * (s & 1) + j];
-      b[j] = (_Float16)tanh_fast(hv);
+      const float av = (s >> 1) ? acc1[8 * (s & 1) + j] : acc0[8 * (s & 1) + j];
+      b[j] = (_Float16)sigmoid_complement(av);
     }
     out = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s * 64 + lane], b, out, 0, 0, 0);
   }
@@ -154,14 +184,14 @@ __global__ void __launch_bounds__(64 * WPB) k_policy_mlp(const Args p, const int
   const bool sample = P.rng != nullptr;
   uint32_t state = 0;
   if (sample) state = P.rng[(int64_t)h * p.n + env];
-  const int choice = pick(out, count, sample, state);
+  const int choice = pick<CMAX>(out, count, sample, state);
   if (valid) {
     P.pairs[env * 2 + h] = choice;
     if (sample) P.rng[(int64_t)h * p.n + env] = state;
     if (P.logits != nullptr) {
 #pragma unroll
-      for (int c = 0; c < 16; c++)
-        if (c < count) P.logits[(int64_t)((h ? 4 : 0) + c) * p.n + env] = out[c];
+      for (int c = 0; c < CMAX; c++)
+        if (c < count) P.logits[(int64_t)((h ? 4 : 0) + c) * p.n + env] = out[c] * K_LN2;   // natural-log logits
     }
   }
 }
@@ -190,9 +220,23 @@ int oc_policy_pack_w1(const float *w1, const float *wt, const float *b1, int32_t
         for (int j = 0; j < 8; j++) {
           const int row = 32 * m + (l & 31), k = 16 * s + 8 * (l >> 5) + j;
           const float v = k < F ? w1[(size_t)row * F + k] : k == F ? wt[row] : k == F + 1 ? b1[row] : 0.0f;
-          out[(((size_t)m * ks + s) * 64 + l) * 8 + j] = f32_to_f16_bits(v);
+          out[(((size_t)m * ks + s) * 64 + l) * 8 + j] = f32_to_f16_bits(2.0f * K_LOG2E * v);
         }
   return 0;
+}
+
+// which logit (0..3 move, 4 + c comm) lives in row o of the second product, or -1
+static int logit_of_row(int o, int C) {
+  if (o < 4) return o;
+  if (((o - 4) & 7) < 4) {
+    const int c = ((o - 4) & 3) + 4 * ((o - 4) >> 3);
+    if (c < C) return 4 + c;
+  }
+  return -1;
+}
+static float w2_folded(const float *w2, int logit, int hid) {   // the fp16 value the kernel multiplies r by
+  const _Float16 hv = (_Float16)(-2.0f * K_LOG2E * w2[(size_t)logit * OC_POLICY_HIDDEN + hid]);
+  return (float)hv;
 }
 
 int oc_policy_pack_w2(const float *w2, int32_t C, uint16_t *out) {
@@ -200,32 +244,25 @@ int oc_policy_pack_w2(const float *w2, int32_t C, uint16_t *out) {
   for (int s = 0; s < 4; s++)
     for (int l = 0; l < 64; l++)
       for (int j = 0; j < 8; j++) {
-        const int o = l & 31, hid = 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
-        // which logit lives in row o: move o (o < 4), else comm c with o = 4 + (c & 3) + 8 (c >> 2)
-        int logit = -1;
-        if (o < 4) logit = o;
-        else if (((o - 4) & 7) < 4) {
-          const int c = ((o - 4) & 3) + 4 * ((o - 4) >> 3);
-          if (c < C) logit = 4 + c;
-        }
-        const float v = logit >= 0 ? w2[(size_t)logit * OC_POLICY_HIDDEN + hid] : 0.0f;
-        out[((size_t)s * 64 + l) * 8 + j] = f32_to_f16_bits(v);
+        const int logit = logit_of_row(l & 31, C), hid = 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+        out[((size_t)s * 64 + l) * 8 + j] = f32_to_f16_bits(logit >= 0 ? w2_folded(w2, logit, hid) : 0.0f);
       }
   return 0;
 }
 
-int oc_policy_pack_b2(const float *b2, int32_t C, float *out) {
-  if (!b2 || !out || C < 1 || C > OC_POLICY_MAX_COMM) return fail("oc_policy_pack_b2: bad argument (1 <= C <= 16)");
+int oc_policy_pack_b2(const float *b2, const float *w2, int32_t C, float *out) {
+  if (!b2 || !w2 || !out || C < 1 || C > OC_POLICY_MAX_COMM)
+    return fail("oc_policy_pack_b2: bad argument (1 <= C <= 16)");
   for (int l = 0; l < 64; l++)
     for (int r = 0; r < 16; r++) {
-      const int o = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-      int logit = -1;
-      if (o < 4) logit = o;
-      else if (((o - 4) & 7) < 4) {
-        const int c = ((o - 4) & 3) + 4 * ((o - 4) >> 3);
-        if (c < C) logit = 4 + c;
+      const int logit = logit_of_row((r & 3) + 8 * (r >> 2) + 4 * (l >> 5), C);
+      float v = 0.0f;
+      if (logit >= 0) {   // log2(e) (b2 + sum_j W2[j]), the sum taken over the ROUNDED folded weights
+        float sum = 0.0f;
+        for (int j = 0; j < OC_POLICY_HIDDEN; j++) sum += w2_folded(w2, logit, j);
+        v = K_LOG2E * b2[logit] - 0.5f * sum;
       }
-      out[l * 16 + r] = logit >= 0 ? b2[logit] : 0.0f;
+      out[l * 16 + r] = v;
     }
   return 0;
 }
@@ -236,6 +273,7 @@ int oc_policy_mlp(const oc_policy_player *players, int32_t num_players, const do
       obs_type < 0 || obs_type > 2 || n < 0)
     return fail("oc_policy_mlp: bad argument (1..2 players, 1 <= C <= 16, obs_type 0..2)");
   if (n == 0) return 0;
+  if ((int64_t)F * n >= ((int64_t)1 << 31)) return fail("oc_policy_mlp: F * n must stay below 2^31; split the batch");
   Args a;
   memset(&a, 0, sizeof(a));
   for (int k = 0; k < num_players; k++) {
@@ -250,14 +288,21 @@ int oc_policy_mlp(const oc_policy_player *players, int32_t num_players, const do
   const int64_t gx = (n + 32 * wpb - 1) / (32 * wpb), gx8 = (gx + 7) / 8 * 8;
   if (gx8 * num_players > 0x7FFFFFFF) return fail("oc_policy_mlp: n too large");
   const dim3 g((unsigned)(gx8 * num_players)), b(64 * wpb);
-#define OC_PL(OT_)                                                                                          \
+#define OC_PL2(OT_, CM_)                                                                                    \
   do {                                                                                                      \
-    if (wpb == 2) hipLaunchKernelGGL((k_policy_mlp<OT_, 2>), g, b, 0, (hipStream_t)stream, a, (int)gx, (int)gx8); \
-    else hipLaunchKernelGGL((k_policy_mlp<OT_, 1>), g, b, 0, (hipStream_t)stream, a, (int)gx, (int)gx8);    \
+    if (wpb == 2) hipLaunchKernelGGL((k_policy_mlp<OT_, 2, CM_>), g, b, 0, (hipStream_t)stream, a, (int)gx, (int)gx8); \
+    else hipLaunchKernelGGL((k_policy_mlp<OT_, 1, CM_>), g, b, 0, (hipStream_t)stream, a, (int)gx, (int)gx8); \
+  } while (0)
+#define OC_PL(OT_)                 \
+  do {                             \
+    if (C <= 4) OC_PL2(OT_, 4);    \
+    else if (C <= 8) OC_PL2(OT_, 8); \
+    else OC_PL2(OT_, 16);          \
   } while (0)
   if (obs_type == 1) OC_PL(1);
   else if (obs_type == 2) OC_PL(2);
   else OC_PL(0);
+#undef OC_PL2
 #undef OC_PL
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

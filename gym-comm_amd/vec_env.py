@@ -210,7 +210,7 @@ class FusedMLPPartner:
     """An ``MLPPolicy`` in the partner (or ego) seat as ONE launch of the hand-written policy
     kernel (include/oc_policy.h, csrc/oc_policy.hip): both products on the matrix cores
     (v_mfma_f32_32x32x16_f16, one wave = 32 envs, the hidden layer never leaves the accumulator
-    registers), tanh, Gumbel-max sampling from two PCG32 streams per env, and the result written as
+    registers), tanh, a categorical sample from two PCG32 streams per env, and the result written as
     the int32 [n][2] (move, comm) pairs the step kernel consumes as they lie.  What
     ``TorchPolicyPartner(MLPPolicy(...))`` does in ~12 torch launches.  Two of them (ego + partner)
     share one launch (``FusedMLPPartner.launch``).  Weights are packed once (``refresh()`` after an
@@ -248,7 +248,7 @@ class FusedMLPPartner:
         for rc, what in ((L.oc_policy_pack_w1(fp(w1), fp(wt.reshape(-1)), fp(b1.reshape(-1)), self.F,
                                               o1.ctypes.data_as(ctypes.c_void_p)), "oc_policy_pack_w1"),
                          (L.oc_policy_pack_w2(fp(w2), self.C, o2.ctypes.data_as(ctypes.c_void_p)), "oc_policy_pack_w2"),
-                         (L.oc_policy_pack_b2(fp(b2.reshape(-1)), self.C, fp(ob)), "oc_policy_pack_b2")):
+                         (L.oc_policy_pack_b2(fp(b2.reshape(-1)), fp(w2), self.C, fp(ob)), "oc_policy_pack_b2")):
             if rc:
                 raise _lib.OcError("%s failed: %s" % (what, L.oc_policy_last_error().decode()))
         dev = self.device

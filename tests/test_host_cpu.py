@@ -139,14 +139,20 @@ def test_policy_library_exports_its_header_and_packs_fragments_as_documented():
         ob = np.zeros((64, 16), np.float32)
         assert L.oc_policy_pack_w1(fp(w1), fp(wt), fp(b1), F, o1.ctypes.data_as(ctypes.c_void_p)) == 0
         assert L.oc_policy_pack_w2(fp(w2), C, o2.ctypes.data_as(ctypes.c_void_p)) == 0
-        assert L.oc_policy_pack_b2(fp(b2), C, fp(ob)) == 0
+        assert L.oc_policy_pack_b2(fp(b2), fp(w2), C, fp(ob)) == 0
+        # the activation's constants are folded in: 2 log2(e) into the first layer; the second takes
+        # r = 1 / (2^a + 1) with -2 log2(e) W2 and starts at log2(e) (b2 + the row sum of W2)
+        LE = np.float32(1.4426950408889634)
         aug = np.zeros((64, 16 * ks), np.float32)
         aug[:, :F], aug[:, F], aug[:, F + 1] = w1, wt, b1
+        aug = (np.float32(2) * LE * aug).astype(np.float32)
         row_of = {o: o for o in range(4)}                       # logit -> row of the second product
         row_of.update({4 + c: 4 + (c & 3) + 8 * (c >> 2) for c in range(C)})
         w2row, b2row = np.zeros((32, 64), np.float32), np.zeros(32, np.float32)
         for logit, o in row_of.items():
-            w2row[o], b2row[o] = w2[logit], b2[logit]
+            w2row[o] = (np.float32(-2) * LE * w2[logit]).astype(np.float32)
+            folded = w2row[o].astype(np.float16).astype(np.float32)
+            b2row[o] = LE * b2[logit] - np.float32(0.5) * np.float32(sum(float(v) for v in folded))
         for l in range(64):
             r, h = l & 31, l >> 5
             for j in range(8):
@@ -156,7 +162,7 @@ def test_policy_library_exports_its_header_and_packs_fragments_as_documented():
                 for s_ in range(4):
                     assert o2[s_, l, j] == f16(w2row[r, 16 * s_ + 8 * (j >> 2) + 4 * h + (j & 3)])
             for reg in range(16):
-                assert ob[l, reg] == b2row[(reg & 3) + 8 * (reg >> 2) + 4 * h]
+                assert abs(ob[l, reg] - b2row[(reg & 3) + 8 * (reg >> 2) + 4 * h]) < 1e-5
     assert L.oc_policy_pack_w2(fp(np.zeros((21, 64), np.float32)), 17, o2.ctypes.data_as(ctypes.c_void_p)) != 0
     assert b"C <= 16" in L.oc_policy_last_error()
     assert L.oc_policy_mlp(None, 1, None, 29, 2, 0, 0, None) != 0      # argument errors before any launch
