@@ -142,3 +142,31 @@ def test_fused_policies_drive_the_closed_loop():
             assert torch.equal(vg._b.state, ve._b.state) and torch.equal(vg._b.obs, ve._b.obs), k
             assert torch.equal(ego_g.pairs, ego_e.pairs) and torch.equal(alt_g._rng, alt_e._rng), k
     assert int(ve._b.done.sum()) >= 0 and ve._b.read_metrics()["env_steps"] == 12 * n
+
+
+def test_refresh_repacks_in_place_and_a_captured_graph_sees_the_new_weights():
+    """After an optimiser step the module's weights change: refresh() re-packs them into the SAME
+    device buffers, so a hipGraph captured earlier evaluates the new network."""
+    from gym_comm_amd.vec_env import FusedMLPPartner, MLPPolicy
+    env = _stepped_env("open-divider_tomato", 640, 2, torch.int32)
+    pol = MLPPolicy(env.S, 2, seed=4).cuda()
+    fused = FusedMLPPartner(pol, sample=False, keep_logits=True)
+    rows = env.obs[0]
+    FusedMLPPartner.launch([fused], [rows], env.timestep)       # warm-up (module load) before the capture
+    torch.cuda.synchronize()
+    ptrs = [t.data_ptr() for t in fused._w]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        FusedMLPPartner.launch([fused], [rows], env.timestep)
+    g.replay()
+    before = fused.logits.clone()
+    assert float((before - _reference_logits(pol, rows, env.timestep)).abs().max()) < 2e-2
+    with torch.no_grad():
+        pol.w2.mul_(-1.5)
+        pol.b1.add_(0.25)
+    fused.refresh()
+    assert [t.data_ptr() for t in fused._w] == ptrs
+    g.replay()
+    after = fused.logits.clone()
+    assert float((after - _reference_logits(pol, rows, env.timestep)).abs().max()) < 2e-2
+    assert float((after - before).abs().max()) > 0.1
