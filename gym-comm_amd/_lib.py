@@ -170,3 +170,32 @@ def load_policy(path=None):
     L._oc_path = path
     _libs[path] = L
     return L
+
+
+HOSTIO_ABI_VERSION = 1   # include/oc_hostio.h: OC_HOSTIO_ABI_VERSION
+HOSTIO_SYMBOLS = ["oc_hostio_abi_version", "oc_hostio_last_error", "oc_pack_host_bytes", "oc_pack_host"]
+
+
+def load_hostio(path=None):
+    """Load (once) and type liboc_hostio.so (include/oc_hostio.h): the numpy boundary's pack kernel."""
+    path = os.path.abspath(path or os.environ.get("OC_HOSTIO_LIB") or _build.HOSTIO_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise OcError(
+            "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (there is no CPU fallback)" % path)
+    _preload_torch_hip_runtime()
+    L = ctypes.CDLL(path)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.oc_hostio_abi_version.restype = ctypes.c_int
+    L.oc_hostio_last_error.restype = ctypes.c_char_p
+    L.oc_pack_host_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32, i64]
+    L.oc_pack_host_bytes.restype = i64
+    L.oc_pack_host.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.oc_pack_host.restype = ctypes.c_int
+    if L.oc_hostio_abi_version() != HOSTIO_ABI_VERSION:
+        raise OcError("liboc_hostio.so ABI version mismatch")
+    L._oc_path = path
+    _libs[path] = L
+    return L

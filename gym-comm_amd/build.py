@@ -18,6 +18,10 @@ POLICY_SOURCES = ["oc_policy.hip"]
 POLICY_HEADERS = ["oc_policy.h"]
 POLICY_LIB = os.path.join(CSRC, "liboc_policy.so")
 POLICY_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# the host-I/O library (include/oc_hostio.h): the numpy boundary's pack-for-PCIe kernel
+HOSTIO_SOURCES = ["oc_hostio.hip"]
+HOSTIO_HEADERS = ["oc_hostio.h"]
+HOSTIO_LIB = os.path.join(CSRC, "liboc_hostio.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
@@ -75,6 +79,14 @@ def build_policy(force=False, verbose=False):
     return _compile(POLICY_LIB, POLICY_SOURCES, POLICY_FLAGS, verbose)
 
 
+def build_hostio(force=False, verbose=False):
+    """Compile the numpy boundary's pack kernel (include/oc_hostio.h) into csrc/liboc_hostio.so."""
+    if not force and not needs_build(HOSTIO_LIB, HOSTIO_SOURCES, HOSTIO_HEADERS):
+        return HOSTIO_LIB
+    return _compile(HOSTIO_LIB, HOSTIO_SOURCES, POLICY_FLAGS, verbose)
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
     print(build_policy(force=True, verbose=True))
+    print(build_hostio(force=True, verbose=True))

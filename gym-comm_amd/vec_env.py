@@ -365,7 +365,7 @@ class ClosedLoop:
 class OvercookedVecEnv(_VecEnvBase):
     def __init__(self, arglist, num_envs, partner=None, device="cuda", terminal_obs=False,
                  ego_agent_idx=0, subtask_order=None, level_dir=None, seed=0,
-                 track_episode_stats=True, use_graph=False, **batched_kw):
+                 track_episode_stats=True, use_graph=False, reuse_host_buffers=False, **batched_kw):
         if _arg(arglist, "num_agents") != 2:
             raise ValueError("the gym_comm wrapper drives exactly 2 agents")
         self.arglist = arglist
@@ -401,6 +401,13 @@ class OvercookedVecEnv(_VecEnvBase):
         self._env_views = {}                             # env index -> (OvercookedEnvironment view, version)
         self._use_graph = bool(use_graph) and not self.terminal_obs
         self._ego_pairs = None
+        self._act_pinned = None
+        self._host_stats = None
+        # numpy API: False = every step returns fresh arrays (a host copy out of the pinned
+        # buffer); True = the arrays are views of two alternating pinned buffers, valid until
+        # the step after next (what a rollout collector that copies them on arrival needs)
+        self._reuse_host = bool(reuse_host_buffers)
+        self._host_flip = 0
 
     @property
     def partner(self):
@@ -583,64 +590,66 @@ class OvercookedVecEnv(_VecEnvBase):
     def _to_numpy(obs):
         return {k: v.cpu().numpy().astype(SPACE_DTYPE[k]) for k, v in obs.items()}
 
+    def _host_plan(self):
+        """The pack plan of the numpy boundary (include/oc_hostio.h): which observation row goes
+        to which column of which dtype block (int64 / float32 / int8 as the declared spaces,
+        overcooked_env.py:41-85), the device and pinned host buffers, and the numpy views' offsets."""
+        b, n = self._b, self.num_envs
+        L = _lib.load_hostio()
+        block_of = {np.dtype(np.int64): 0, np.dtype(np.float32): 1, np.dtype(np.int8): 2}
+        width, plan, cols = [0, 0, 0], np.zeros(b.F, np.int32), {}
+        for k, (lo, hi) in b._layout.items():
+            blk = block_of[np.dtype(SPACE_DTYPE[k])]
+            cols[k] = (blk, width[blk], width[blk] + hi - lo)
+            for r in range(lo, hi):
+                plan[r] = (blk << 16) | width[blk]
+                width[blk] += 1
+        stats = b.ep_return is not None
+        total = int(L.oc_pack_host_bytes(width[0], width[1], width[2], 1, int(stats), 1, int(stats), n))
+        off, o = {}, 0
+        for name, nbytes in (("b64", n * width[0] * 8), ("ret", n * 8 if stats else 0), ("b32", n * width[1] * 4),
+                             ("ts", n * 4), ("rew", n * 4), ("done", n * 4), ("len", n * 4 if stats else 0),
+                             ("b8", n * width[2])):
+            off[name] = (o, o + nbytes)
+            o += nbytes
+        assert o == total
+        return {"L": L, "plan": torch.from_numpy(plan).to(b.device), "width": width, "cols": cols, "stats": stats,
+                "dev": torch.empty(max(total, 1), dtype=torch.uint8, device=b.device),
+                "pinned": [torch.empty(max(total, 1), dtype=torch.uint8, pin_memory=True)
+                           for _ in range(2 if self._reuse_host else 1)], "off": off,
+                "ot": {torch.int32: 0, torch.int8: 1, torch.float32: 2}[b.obs.dtype]}
+
     def _host_step(self, rew=None, done=None):
-        """Everything the numpy API returns for one step, in ONE device->host copy.  The ego
-        viewer's [F][n] rows are gathered by target dtype (int64 / float32 / int8 as the
-        declared spaces, overcooked_env.py:41-85), transposed and cast on the GPU; those
-        blocks, the float32 timestep, the float32 reward and the done flags are concatenated
-        as bytes (widest elements first, so every block stays aligned) and cross PCIe together;
-        the per-key arrays are column views of the host copy (no host-side casts)."""
-        b = self._b
-        if self._dtype_groups is None:
-            groups = {}
-            for k, (lo, hi) in b._layout.items():
-                groups.setdefault(SPACE_DTYPE[k], []).append((k, lo, hi))
-            self._dtype_groups = []
-            for dt in sorted(groups, key=lambda d: -np.dtype(d).itemsize):
-                keys = groups[dt]
-                rows = torch.tensor([r for _, lo, hi in keys for r in range(lo, hi)], device=b.device)
-                cols, c = {}, 0
-                for k, lo, hi in keys:
-                    cols[k] = (c, c + hi - lo)
-                    c += hi - lo
-                self._dtype_groups.append((np.dtype(dt), getattr(torch, np.dtype(dt).name), rows, cols, c))
-        n = self.num_envs
-        parts, plan = [], []            # device byte blocks; (name, numpy dtype, shape, cols)
-        for ndt, tdt, rows, cols, width in self._dtype_groups:
-            parts.append(b.obs[0].index_select(0, rows).T.to(tdt).contiguous())
-            plan.append(("obs", ndt, (n, width), cols))
-        f32 = [("timestep", b.timestep)] + ([("rew", rew)] if rew is not None else [])
-        for name, t in f32:
-            parts.append(t.to(torch.float32))
-            plan.append((name, np.dtype(np.float32), (n,), None))
-        if done is not None:
-            parts.append(done)
-            plan.append(("done", np.dtype(np.int32), (n,), None))
-        # order by element size, widest first (stable): offsets stay multiples of the element size
-        order = sorted(range(len(parts)), key=lambda i: -plan[i][1].itemsize)
-        # small batches are latency-bound (one copy instead of six: 268 -> 235 us at n = 4096);
-        # large ones are bandwidth-bound and the byte-wise concatenation only adds a pass
-        # (1.6 -> 2.4 ms at n = 131072), so there every block crosses on its own
-        single = n <= 16384
-        if single:
-            host = torch.cat([parts[i].reshape(-1).view(torch.uint8) for i in order]).cpu().numpy()
-        out, obs, off = {}, {}, 0
-        for i in order:
-            name, ndt, shape, cols = plan[i]
-            nb = int(np.prod(shape)) * ndt.itemsize
-            if single:
-                arr = host[off:off + nb].view(ndt).reshape(shape)
-            else:
-                arr = parts[i].cpu().numpy().reshape(shape)
-            off += nb
-            if name == "obs":
-                for k, (lo, hi) in cols.items():
-                    obs[k] = arr[:, lo:hi]
-            elif name == "timestep":
-                obs["timestep"] = arr.reshape(-1, 1)
-            else:
-                out[name] = arr
-        return obs, out.get("rew"), out.get("done")
+        """Everything the numpy API returns for one step: ONE launch (``oc_pack_host``,
+        include/oc_hostio.h: the ego viewer's [F][n] rows gathered by target dtype, transposed
+        and converted; float32 timestep and reward, done flags, episode return / length) into one
+        device buffer, ONE device->host copy into pinned memory, and a host copy out of it (the
+        caller may keep the arrays); the per-key arrays are column views of that copy."""
+        b, n = self._b, self.num_envs
+        hp = self._dtype_groups
+        if hp is None:
+            hp = self._dtype_groups = self._host_plan()
+        dp = lambda t: None if t is None else t.data_ptr()
+        with b._on_device():
+            rc = hp["L"].oc_pack_host(b.obs[0].data_ptr(), hp["ot"], b.F, hp["plan"].data_ptr(), hp["width"][0],
+                                      hp["width"][1], hp["width"][2], b.timestep.data_ptr(),
+                                      b.shaped_reward.data_ptr(), dp(b.ep_return), b.done.data_ptr(),
+                                      dp(b.ep_length), hp["dev"].data_ptr(), n, b._raw_stream())
+        if rc:
+            raise _lib.OcError("oc_pack_host failed (%d): %s" % (rc, hp["L"].oc_hostio_last_error().decode()))
+        self._host_flip ^= 1
+        pinned = hp["pinned"][self._host_flip if self._reuse_host else 0]
+        pinned.copy_(hp["dev"], non_blocking=True)
+        torch.cuda.current_stream(b.device).synchronize()
+        host = pinned.numpy() if self._reuse_host else pinned.numpy().copy()
+        view = lambda name, dt, shape: host[hp["off"][name][0]:hp["off"][name][1]].view(dt).reshape(shape)
+        blocks = (view("b64", np.int64, (n, hp["width"][0])), view("b32", np.float32, (n, hp["width"][1])),
+                  view("b8", np.int8, (n, hp["width"][2])))
+        obs = {k: blocks[blk][:, lo:hi] for k, (blk, lo, hi) in hp["cols"].items()}
+        obs["timestep"] = view("ts", np.float32, (n, 1))
+        self._host_stats = ((view("ret", np.float64, (n,)), view("len", np.int32, (n,))) if hp["stats"] else None)
+        return (obs, view("rew", np.float32, (n,)) if rew is not None else None,
+                view("done", np.int32, (n,)) if done is not None else None)
 
     def _ego_obs_numpy(self):
         return self._host_step()[0]
@@ -653,7 +662,14 @@ class OvercookedVecEnv(_VecEnvBase):
         self._pending = np.asarray(actions)
 
     def step_wait(self):
-        _, rew, done = self.step_tensors(torch.from_numpy(self._pending.astype(np.int32)))
+        # host actions -> pinned staging -> the device pairs the kernel consumes as they lie
+        if self._act_pinned is None:
+            self._act_pinned = torch.empty((self.num_envs, 2), dtype=torch.int32, pin_memory=True)
+            if self._ego_pairs is None:
+                self._ego_pairs = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self._b.device)
+        np.copyto(self._act_pinned.numpy(), self._pending.reshape(self.num_envs, 2), casting="unsafe")
+        self._ego_pairs.copy_(self._act_pinned, non_blocking=True)
+        _, rew, done = self.step_tensors(self._ego_pairs)
         obs_np, rew_np, done_i32 = self._host_step(rew, done)
         done_np = done_i32.astype(bool)
         infos = self._infos                       # the same list every step (as DummyVecEnv's buf_infos)
@@ -664,9 +680,9 @@ class OvercookedVecEnv(_VecEnvBase):
         if len(idx):
             term = self._to_numpy(self._last_terminal) if self._last_terminal is not None else None
             if self.track_episode_stats:
-                # after a step that returned done the kernel's rows hold the finished episode's totals
-                ret = self._b.ep_return.cpu().numpy()
-                ln = self._b.ep_length.cpu().numpy()
+                # after a step that returned done the kernel's rows hold the finished episode's
+                # totals; they crossed PCIe with the observation (oc_pack_host)
+                ret, ln = self._host_stats
             for i in idx:
                 if self.track_episode_stats:
                     infos[i]["episode"] = {"r": float(ret[i]), "l": int(ln[i])}     # Monitor-style

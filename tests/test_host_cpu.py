@@ -168,6 +168,23 @@ def test_policy_library_exports_its_header_and_packs_fragments_as_documented():
     assert L.oc_policy_mlp(None, 1, None, 29, 2, 0, 0, None) != 0      # argument errors before any launch
 
 
+def test_hostio_library_exports_its_header():
+    """liboc_hostio.so (include/oc_hostio.h: the numpy boundary's pack kernel) loads without a
+    GPU, exports what its header declares, and sizes its buffer as documented."""
+    from gym_comm_amd import _lib, build
+    build.build_hostio()
+    hdr = open(os.path.join(ROOT, "include", "oc_hostio.h")).read()
+    declared = re.findall(r"OC_API\s+[\w\s\*]+?\b(oc_\w+)\s*\(", hdr)
+    assert sorted(declared) == sorted(_lib.HOSTIO_SYMBOLS)
+    L = _lib.load_hostio()
+    assert L.oc_hostio_abi_version() == _lib.HOSTIO_ABI_VERSION == 1
+    n = 1000
+    assert L.oc_pack_host_bytes(8, 4, 17, 1, 1, 1, 1, n) == n * (8 * 8 + 8 + 4 * 4 + 4 + 4 + 4 + 4 + 17)
+    assert L.oc_pack_host_bytes(8, 4, 17, 0, 0, 0, 0, n) == n * (8 * 8 + 4 * 4 + 4 + 17)
+    assert L.oc_pack_host(None, 0, 29, None, 8, 4, 17, None, None, None, None, None, None, 0, None) != 0
+    assert b"oc_pack_host" in L.oc_hostio_last_error()
+
+
 def test_product_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

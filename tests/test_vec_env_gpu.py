@@ -261,3 +261,42 @@ def test_per_env_views_of_a_batch_match_the_oracle_render(oracle_lib):
     assert len(rec.episodes) >= 2 * (K // T)
     for i, ep, frames in rec.episodes:
         assert i in (0, 4095) and 1 <= len(frames) <= T and all(isinstance(f, str) for f in frames)
+
+
+@pytest.mark.gpu
+def test_numpy_api_arrays_with_and_without_reused_host_buffers():
+    """The numpy boundary through oc_pack_host (include/oc_hostio.h): the arrays have the declared
+    dtypes and equal the device tensors; by default they are fresh every step; with
+    reuse_host_buffers=True they are views of two alternating pinned buffers (valid until the
+    step after next) with the same contents."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from gym_comm_amd.vec_env import OvercookedVecEnv, SPACE_DTYPE
+    arg = SimpleNamespace(level="open-divider_salad", num_agents=2, max_num_timesteps=30, ego_config={},
+                          partner_config={}, num_communication=3, communication_on=True, ego_led=False,
+                          fow_radius=1)
+    n = 777
+    va = OvercookedVecEnv(arg, n, seed=3)
+    vb = OvercookedVecEnv(arg, n, seed=3, reuse_host_buffers=True)
+    oa, ob = va.reset(), vb.reset()
+    rng = np.random.default_rng(0)
+    kept = []
+    for k in range(70):
+        acts = np.stack([rng.integers(0, 4, n), rng.integers(0, 3, n)], axis=1)
+        oa, ra, da, ia = va.step(acts)
+        ob, rb, db, ib = vb.step(acts)
+        dev = va._obs_tensors(0)
+        for key in oa:
+            assert oa[key].dtype == np.dtype(SPACE_DTYPE[key]) == ob[key].dtype, key
+            want = dev[key].cpu().numpy() if key != "timestep" else va._b.timestep.cpu().numpy().reshape(-1, 1)
+            assert np.array_equal(oa[key], want.astype(SPACE_DTYPE[key])), (k, key)
+            assert np.array_equal(oa[key], ob[key]), (k, key)
+        assert ra.dtype == np.float32 and np.array_equal(ra, va._b.shaped_reward.cpu().numpy().astype(np.float32))
+        assert np.array_equal(ra, rb) and np.array_equal(da, db) and da.dtype == bool
+        assert np.array_equal(da, va._b.done.cpu().numpy() != 0)
+        for i in np.nonzero(da)[0][:5]:
+            assert ia[i]["episode"] == ib[i]["episode"] and ia[i]["episode"]["l"] > 0
+        kept.append((oa["object_encodings_x"], oa["object_encodings_x"].copy()))
+    for view, snapshot in kept:            # fresh arrays stay what they were
+        assert np.array_equal(view, snapshot)

@@ -50,16 +50,20 @@ def main():
             dt = timed(lambda k: loop.step(), reps) / k_steps
             print("n=%d ClosedLoop (ego + partner + fused step, %d step(s) per hipGraph replay): %.1f us/step, %.3g env-steps/s"
                   % (n, k_steps, dt * 1e6, n / dt), flush=True)
-        venv = OvercookedVecEnv(arg, n, seed=1)
         acts_np = [a.cpu().numpy() for a in acts]
-        venv.reset()
-        steps = 200 if n <= 4096 else 30
-        t0 = time.perf_counter()
-        for k in range(steps):
-            venv.step(acts_np[k % 64])
-        dt = (time.perf_counter() - t0) / steps
-        print("n=%d numpy API (host actions in, 11 host obs arrays out, PCIe-inclusive): %.1f us/step, %.3g env-steps/s"
-              % (n, dt * 1e6, n / dt), flush=True)
+        for reuse in (False, True):
+            venv = OvercookedVecEnv(arg, n, seed=1, reuse_host_buffers=reuse)
+            venv.reset()
+            for k in range(10):
+                venv.step(acts_np[k % 64])
+            steps = 400 if n <= 4096 else 40
+            t0 = time.perf_counter()
+            for k in range(steps):
+                venv.step(acts_np[k % 64])
+            dt = (time.perf_counter() - t0) / steps
+            print("n=%d numpy API (host actions in, 11 host obs arrays + infos out, PCIe-inclusive; %s): %.1f us/step, %.3g env-steps/s"
+                  % (n, "views of two alternating pinned buffers" if reuse else "fresh arrays every step",
+                     dt * 1e6, n / dt), flush=True)
 
 
 if __name__ == "__main__":
