@@ -22,10 +22,12 @@ the finished step.  ``infos[i]["terminal_observation"]`` is only filled with
 (what SB3's ``Monitor`` adds: ``infos[i]["episode"]``) are kept by the kernel itself.
 
 Partners
-  ``RandomPartner``        uniform random, one launch of the library's own generator kernel;
+  ``RandomPartner``        uniform random, drawn inside the step kernel (no launch of its own);
   ``TorchPolicyPartner``   any ``torch.nn.Module`` mapping the observation dict to (move logits,
                            comm logits) -- the batched stand-in for pantheonrl's
                            ``OnPolicyAgent.get_action`` / ``update`` (agents.py:112-194);
+  ``FusedMLPPartner``      an ``MLPPolicy`` (64 tanh units) as ONE launch of the hand-written MFMA
+                           policy kernel (include/oc_policy.h), ego and partner in the same launch;
   any callable ``partner(obs_dict) -> [n, 2]`` still works (slow path).
 
 ``ClosedLoop`` (``venv.closed_loop(ego)``) captures ego policy -> partner policy -> fused step
@@ -34,7 +36,8 @@ Partners
 
 Subclasses ``stable_baselines3.common.vec_env.VecEnv`` when SB3 is importable; otherwise a
 structural stand-in with the same methods.  ``step_tensors`` is the zero-copy variant for
-policies that live on the GPU.
+policies that live on the GPU; the numpy API packs a step's arrays with one launch of
+``oc_pack_host`` (include/oc_hostio.h) and one PCIe copy.
 """
 import contextlib
 import ctypes
@@ -395,7 +398,7 @@ class OvercookedVecEnv(_VecEnvBase):
         self._views = [None, None]
         self._infos = [{} for _ in range(num_envs)]      # reused; only finished envs are touched
         self._dirty = []
-        self._dtype_groups = None
+        self._host_plan_cache = None
         self._last_terminal = None
         self._version = 0                                # bumped by every step / reset
         self._env_views = {}                             # env index -> (OvercookedEnvironment view, version)
@@ -626,9 +629,9 @@ class OvercookedVecEnv(_VecEnvBase):
         device buffer, ONE device->host copy into pinned memory, and a host copy out of it (the
         caller may keep the arrays); the per-key arrays are column views of that copy."""
         b, n = self._b, self.num_envs
-        hp = self._dtype_groups
+        hp = self._host_plan_cache
         if hp is None:
-            hp = self._dtype_groups = self._host_plan()
+            hp = self._host_plan_cache = self._host_plan()
         dp = lambda t: None if t is None else t.data_ptr()
         with b._on_device():
             rc = hp["L"].oc_pack_host(b.obs[0].data_ptr(), hp["ot"], b.F, hp["plan"].data_ptr(), hp["width"][0],

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the fused step as ONE wave per 64 envs (OC_SPLIT=1) against the split launches
+# GPU box: the fused step as ONE wave per 64 envs (--waves-per-64 1) against the split launch
 # (4 waves per 64 envs, see multi_step_body in csrc/oc_kernels.hip) over the batch size --
 # what the launcher's split policy (split_for()) rests on.
 LEVEL=${1:-open-divider_tomato}
