@@ -109,6 +109,9 @@ def parse(argv=None):
     p.add_argument("--policy", default="fused", choices=["fused", "torch"],
                    help="closed-loop: the two MLP policies as ONE launch of the hand-written MFMA kernel "
                         "(include/oc_policy.h) or as torch modules (~12 launches each)")
+    p.add_argument("--closed-loop-launches", default="auto", choices=["auto", "1", "2"],
+                   help="closed-loop, --policy fused: launches per step -- 1 = the step kernel evaluates both "
+                        "policies itself (oc_step_opts.policy), 2 = policy kernel + step; auto = 1 where possible")
     p.add_argument("--waves-per-64", type=int, default=0, choices=[0, 1, 4],
                    help="launch hint of the fused step: 0 = the library decides (split launch up to 16384 envs), "
                         "1 = one wave per 64 envs, 4 = split launch (include/oc_hip.h, oc_step_opts)")
@@ -301,7 +304,10 @@ def main():
         ego = seat(MLPPolicy(env.S, args.comm, hidden=args.hidden, seed=seed + 3).to(dev), seed + 4)
         with torch.cuda.stream(stream):
             venv.reset_tensors()
-            loop = venv.closed_loop(ego, graph=False)  # ego fwd -> partner fwd -> step (+ stats in-kernel)
+            # ego fwd -> partner fwd -> step (+ stats in-kernel); --closed-loop-launches 1: the step
+            # kernel evaluates both policies itself (oc_step_opts.policy), 2: policy kernel + step
+            one = {"auto": None, "1": True, "2": False}[args.closed_loop_launches] if fused else None
+            loop = venv.closed_loop(ego, graph=False, one_launch=one)
         step_fn = lambda k: loop.enqueue()             # captured K at a time by StepBlocks below
         obs_elem = 4
     else:
@@ -445,6 +451,8 @@ def main():
                        "max_num_timesteps": args.T, "launch": "hipgraph" if use_graph else "eager",
                        "obs_dtype": (args.obs_dtype if args.policy == "fused" else "float32") if closed else args.obs_dtype,
                        "kernel_flavour": env.kernel_flavour,
+                       **({"launches_per_step": (1 if loop.one_launch else 2) if args.policy == "fused" else "torch"}
+                          if closed else {}),
                        "waves_per_64_envs": env.launch_waves_per_64 if wrapper else 1,
                        "parallelism": "env-sharded x%d" % world},
             "agent_steps_per_sec": value * lv.num_agents,

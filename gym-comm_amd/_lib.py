@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 _I32P = ctypes.POINTER(ctypes.c_int32)
-ABI_VERSION = 4          # include/oc_hip.h: OC_ABI_VERSION
+ABI_VERSION = 5          # include/oc_hip.h: OC_ABI_VERSION
 
 SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destroy",
            "oc_level_spec_source", "oc_is_specialized", "oc_level_subtask_info",
@@ -28,12 +28,18 @@ class WrapCfg(ctypes.Structure):
                 ("can_move_mask", ctypes.c_int32)]
 
 
+class StepPolicy(ctypes.Structure):
+    """oc_step_policy (include/oc_hip.h): one player's packed MLP for oc_step_opts.policy."""
+    _fields_ = [("w1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p), ("rng", ctypes.c_void_p)]
+
+
 class StepOpts(ctypes.Structure):
     """oc_step_opts (include/oc_hip.h): optional device pointers of oc_multi_step."""
     _fields_ = [("ep_return", ctypes.c_void_p), ("ep_length", ctypes.c_void_p),
                 ("ego_pairs", ctypes.c_void_p), ("alt_pairs", ctypes.c_void_p),
                 ("alt_rng", ctypes.c_void_p), ("alt_played", ctypes.c_void_p),
-                ("pairs_int64", ctypes.c_int32), ("waves_per_64", ctypes.c_int32)]
+                ("pairs_int64", ctypes.c_int32), ("waves_per_64", ctypes.c_int32),
+                ("policy", ctypes.POINTER(StepPolicy))]
 
 
 POLICY_ABI_VERSION = 1   # include/oc_policy.h: OC_POLICY_ABI_VERSION

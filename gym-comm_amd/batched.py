@@ -119,6 +119,7 @@ class BatchedOvercooked:
                                       (2 if self.partner_config["CAN_MOVE"] else 0))
         self._layout = obs_layout(self.S, self.C)
         self._ms_args = None
+        self._policy_arr = None
         # random-* levels: item start cells differ per env and per episode
         self.placement = None
         self.rng = None
@@ -219,13 +220,18 @@ class BatchedOvercooked:
 
     def multi_step(self, actions: Optional[torch.Tensor] = None, auto_reset: Optional[bool] = None,
                    ego_pairs: Optional[torch.Tensor] = None, alt_pairs: Optional[torch.Tensor] = None,
-                   alt_rng: Optional[torch.Tensor] = None, alt_played: Optional[torch.Tensor] = None):
+                   alt_rng: Optional[torch.Tensor] = None, alt_played: Optional[torch.Tensor] = None,
+                   policy=None):
         """gym_comm wrapper step in one launch.  actions: int32 [4][n] = ego move (0..3),
         ego comm, alt move, alt comm.  Per player the (move, comm) may instead come as an
         int32 or int64 [n][2] tensor of pairs (`ego_pairs` / `alt_pairs`: a policy's [n, 2] output as it
         lies), and the partner may be drawn by the kernel itself, uniformly, from a per-env
         PCG32 stream (`alt_rng`, int32/uint32 [n]; `alt_played` int32 [2][n] receives the draw)
-        -- include/oc_hip.h, oc_step_opts.  Returns (obs, timestep, shaped_reward f64[n], done)."""
+        -- include/oc_hip.h, oc_step_opts.  `policy`: a pair of device-address tuples
+        (w1, w2, b2, rng or None) -- the two players' packed MLPs (include/oc_policy.h): the kernel
+        evaluates them behind the step and overwrites `ego_pairs` / `alt_pairs` (int32) with the
+        NEXT step's actions: the closed loop in one launch.
+        Returns (obs, timestep, shaped_reward f64[n], done)."""
         n = self.n
         if actions is not None:
             self._check_tensor(actions, (4, n), torch.int32, "actions")
@@ -243,12 +249,20 @@ class BatchedOvercooked:
         if alt_played is not None:
             self._check_tensor(alt_played, (2, n), torch.int32, "alt_played")
         ptr = lambda t: None if t is None else t.data_ptr()
+        if policy is not None:
+            if ego_pairs is None or alt_pairs is None or pdt is not torch.int32 or alt_rng is not None:
+                raise ValueError("policy= needs int32 ego_pairs and alt_pairs (it overwrites them) and no alt_rng")
+            if self._policy_arr is None:
+                self._policy_arr = (_lib.StepPolicy * 2)()
+            for k, (w1, w2, b2, rng) in enumerate(policy):
+                self._policy_arr[k] = _lib.StepPolicy(w1, w2, b2, rng)
         self.multi_step_raw(ptr(actions) or 0, ptr(ego_pairs), ptr(alt_pairs), ptr(alt_rng), ptr(alt_played),
-                            int(self.auto_reset if auto_reset is None else auto_reset), pdt is torch.int64)
+                            int(self.auto_reset if auto_reset is None else auto_reset), pdt is torch.int64,
+                            policy=self._policy_arr if policy is not None else None)
         return self.obs, self.timestep, self.shaped_reward, self.done
 
     def multi_step_raw(self, actions_ptr, ego_pairs_ptr, alt_pairs_ptr, alt_rng_ptr, alt_played_ptr, auto_reset,
-                       pairs_int64=False):
+                       pairs_int64=False, policy=None):
         """multi_step on raw device addresses (int, None = absent), nothing checked: the per-call
         cost is one ctypes call.  For callers that validated their tensors once (vec_env)."""
         a = self._ms_args
@@ -263,6 +277,7 @@ class BatchedOvercooked:
         o = self._ms_opts
         o.ego_pairs, o.alt_pairs, o.alt_rng, o.alt_played = ego_pairs_ptr, alt_pairs_ptr, alt_rng_ptr, alt_played_ptr
         o.pairs_int64 = 1 if pairs_int64 else 0
+        o.policy = policy if policy is not None else None    # (_lib.StepPolicy * 2) or NULL
         a[3] = actions_ptr
         a[10] = auto_reset
         a[16] = self._raw_stream()

@@ -11,6 +11,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["oc_kernels.hip"]
 HEADERS = ["oc_hip.h", "oc_level.h"]          # include/: what SOURCES include
+LOCAL_HEADERS = ["oc_policy_device.h"]        # csrc/: the policy's device code, shared with POLICY_SOURCES
 LIB = os.path.join(CSRC, "liboc_hip.so")
 # the policy library (include/oc_policy.h): its own translation unit and shared object, so that
 # the stepper's specialised builds neither contain nor depend on it
@@ -39,10 +40,10 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC=)")
 
 
-def needs_build(lib=LIB, sources=SOURCES, headers=HEADERS):
+def needs_build(lib=LIB, sources=SOURCES, headers=HEADERS, local_headers=LOCAL_HEADERS):
     if not os.path.exists(lib):
         return True
-    deps = [os.path.join(CSRC, s) for s in sources]
+    deps = [os.path.join(CSRC, s) for s in list(sources) + list(local_headers)]
     inc = os.path.join(CSRC, "..", "..", "include")
     deps += [os.path.join(inc, f) for f in headers]
     return os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps)
@@ -74,14 +75,14 @@ def build(force=False, verbose=False, extra_flags=()):
 
 def build_policy(force=False, verbose=False):
     """Compile the MLP policy kernel (include/oc_policy.h) into csrc/liboc_policy.so."""
-    if not force and not needs_build(POLICY_LIB, POLICY_SOURCES, POLICY_HEADERS):
+    if not force and not needs_build(POLICY_LIB, POLICY_SOURCES, POLICY_HEADERS, LOCAL_HEADERS):
         return POLICY_LIB
     return _compile(POLICY_LIB, POLICY_SOURCES, POLICY_FLAGS, verbose)
 
 
 def build_hostio(force=False, verbose=False):
     """Compile the numpy boundary's pack kernel (include/oc_hostio.h) into csrc/liboc_hostio.so."""
-    if not force and not needs_build(HOSTIO_LIB, HOSTIO_SOURCES, HOSTIO_HEADERS):
+    if not force and not needs_build(HOSTIO_LIB, HOSTIO_SOURCES, HOSTIO_HEADERS, ()):
         return HOSTIO_LIB
     return _compile(HOSTIO_LIB, HOSTIO_SOURCES, POLICY_FLAGS, verbose)
 

@@ -34,6 +34,7 @@
 #include <new>
 
 #include "../../include/oc_hip.h"
+#include "oc_policy_device.h"
 
 namespace {
 
@@ -1555,6 +1556,8 @@ struct MultiArgs {
   int64_t n;
   int32_t auto_reset;
   oc_wrap_cfg cfg;
+  oc_step_policy pol[2]; // opt.policy by value (it is a host pointer), used by the POL variants
+  int32_t pol_ksteps;
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
@@ -1585,7 +1588,13 @@ struct MultiArgs {
 // 32 768 envs (every SIMD has a wave of its own by then), slower beyond: split_for().
 constexpr int DUTY_STATE = 1, DUTY_SHAPE = 2, DUTY_OBS0 = 4, DUTY_OBS1 = 8, DUTY_ALL = 15;
 
-template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int DUTY, bool SPLIT>
+// POL (general variant only): the closed loop in one launch -- behind the step, the wave(s) evaluate
+// both players' MLP policies (oc_policy_device.h) on the observation rows just written and put the
+// NEXT step's (move, comm) pairs where this step read its own (oc_step_opts.policy).  One pass =
+// one wave x 32 envs; a split workgroup gives each of its four waves one (viewer, half) pass
+// behind a second barrier ("every observation row of these 64 envs is written"), a lone wave
+// runs all four.
+template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int DUTY, bool SPLIT, bool POL = false>
 __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int32_t *const actions_,
                                                 int32_t *const comm_, int64_t *const metrics_,
                                                 const int64_t n_, const int32_t block_, const MultiArgs &p) {
@@ -1788,6 +1797,32 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
   OC_STAMP(7);   // every store issued
   if constexpr (D_STATE) slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
   OC_STAMP(8);
+  if constexpr (POL) {
+    static_assert(XO, "the fused policies belong to the general variant");
+    // every observation row (and the timestep) of this workgroup's 64 envs is in memory
+    if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int lane = (int)threadIdx.x & 63;
+    const int C = p.cfg.obs.num_comm, F = 22 + L.S() + 2 * C;
+    const uint32_t n32 = (uint32_t)n_;
+    constexpr int ELEM = OT == 1 ? 1 : 4;
+#pragma unroll
+    for (int v = 0; v < 2; v++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        // a split workgroup: viewer 0 / first half on the OBS0 wave, viewer 1 / first half on OBS1,
+        // the second halves on the STATE and SHAPE waves; a lone wave: all four passes
+        constexpr int mine_split = (DUTY == DUTY_OBS0) ? 0 : (DUTY == DUTY_OBS1) ? 2 : (DUTY == DUTY_STATE) ? 1 : 3;
+        if (SPLIT && (2 * v + q) != mine_split) continue;
+        const int64_t env0 = (int64_t)(i & ~63) + 32 * q + (lane & 31);
+        const bool ok = env0 < n_;
+        const uint32_t env = (uint32_t)(ok ? env0 : n_ - 1);
+        const void *rows = (const char *)p.obs + (size_t)v * F * n_ * ELEM;
+        int32_t *pairs = const_cast<int32_t *>(v == 0 ? p.opt.ego_pairs : p.opt.alt_pairs);
+        ocpol::policy_pass<OT, 4>(rows, n32, env, ok, lane, p.pol[v].w1, p.pol[v].w2, p.pol[v].b2, p.pol[v].rng, pairs,
+                                  nullptr, (float)p.timestep[env], F, C, p.pol_ksteps);
+      }
+  }
 #ifdef OC_STAMPS
   // the sparse-reward pointer doubles as the debug buffer in this build: int64 [waves][16]
   if ((threadIdx.x & 63) == 0 && p.sparse != nullptr) {   // one record per wave, split or not
@@ -1806,7 +1841,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
 // issued without first waiting for a scalar kernarg load.  (block_ = workgroup size | which
 // optional action sources are in use << 16: the branches on them are taken on a preloaded SGPR,
 // not on a pointer that a scalar load has yet to deliver)
-template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int SP>
+template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int SP, bool POL = false>
 __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
                                                     int32_t *const comm_, int64_t *const metrics_,
                                                     const int64_t n_, const int32_t block_,
@@ -1828,9 +1863,9 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   [[maybe_unused]] const MultiArgs &pk = *reinterpret_cast<const MultiArgs *>(
       reinterpret_cast<const char *>((const void *)__builtin_amdgcn_kernarg_segment_ptr()) + offsetof(KernArgs, p));
 #endif
-#define OC_BODY(duty) multi_step_body<M, LDS, OT, WT, DUP, XO, (duty), true>(state_, actions_, comm_, metrics_, n_, block_, pk)
+#define OC_BODY(duty) multi_step_body<M, LDS, OT, WT, DUP, XO, (duty), true, POL>(state_, actions_, comm_, metrics_, n_, block_, pk)
   if constexpr (SP == 1) {
-    multi_step_body<M, LDS, OT, WT, DUP, XO, DUTY_ALL, false>(state_, actions_, comm_, metrics_, n_, block_, p);
+    multi_step_body<M, LDS, OT, WT, DUP, XO, DUTY_ALL, false, POL>(state_, actions_, comm_, metrics_, n_, block_, p);
   } else {
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (role == 0) OC_BODY(DUTY_STATE);
@@ -2511,7 +2546,23 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   if (auto_reset && lv->hdr.nscatter > 0 && !placement && !rng)
     return fail(OC_E_BADARG, "oc_multi_step: auto_reset on a random-placement level needs `placement` or `rng`");
   MultiArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, comm, actions, obs, timestep,
-              reward, done, sparse, metrics, placement, rng, o, n, auto_reset, *cfg};
+              reward, done, sparse, metrics, placement, rng, o, n, auto_reset, *cfg, {}, 0};
+  if (o.policy) {   // the closed loop in one launch (oc_step_opts.policy)
+#ifndef OC_SPECIALIZED
+    return fail(OC_E_BADARG, "oc_multi_step: opts.policy needs a specialised library (this is the generic one)");
+#endif
+    if (!o.ego_pairs || !o.alt_pairs || o.pairs_int64 || o.alt_rng)
+      return fail(OC_E_BADARG, "oc_multi_step: opts.policy needs ego_pairs and alt_pairs (int32) and no alt_rng");
+    if (cfg->obs.num_comm < 1 || cfg->obs.num_comm > 4)
+      return fail(OC_E_BADARG, "oc_multi_step: opts.policy samples at most 4 comm channels; use oc_policy_mlp");
+    for (int k = 0; k < 2; k++) {
+      if (!o.policy[k].w1 || !o.policy[k].w2 || !o.policy[k].b2)
+        return fail(OC_E_BADARG, "oc_multi_step: opts.policy[k] needs w1, w2 and b2");
+      a.pol[k] = o.policy[k];
+    }
+    a.pol_ksteps = (22 + lv->hdr.S + 2 * cfg->obs.num_comm + 2 + 15) / 16;
+    a.opt.policy = nullptr;   // (a host pointer: nothing on the device may look at it)
+  }
   const size_t lds = (size_t)lv->n16 * 16;
   const bool in_lds = tables_in_lds(n);
   const int ot = cfg->obs.obs_int8;   // 0 int32, 1 int8, 2 float32
@@ -2540,7 +2591,21 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   } while (0)
 // (the generic library splits the plain variant only: its build time)
 #ifdef OC_SPECIALIZED
+// general variant + both policies evaluated behind the step (oc_step_opts.policy)
+#define OC_MS_POL(MM, DD)                                                                                       \
+  do {                                                                                                          \
+    if (!wt || in_lds) return fail(OC_E_BADARG, "oc_multi_step: opts.policy needs write-through stores and tables in global memory"); \
+    if (sp == 4) {                                                                                              \
+      if (ot == 1) return launch_ms_split(k_multi_step<MM, false, 1, true, DD, true, 4, true>, 4, a, n, stream); \
+      if (ot == 2) return launch_ms_split(k_multi_step<MM, false, 2, true, DD, true, 4, true>, 4, a, n, stream); \
+      return launch_ms_split(k_multi_step<MM, false, 0, true, DD, true, 4, true>, 4, a, n, stream);             \
+    }                                                                                                           \
+    if (ot == 1) return launch_ms(k_multi_step<MM, false, 1, true, DD, true, 1, true>, a, n, stream, 0);        \
+    if (ot == 2) return launch_ms(k_multi_step<MM, false, 2, true, DD, true, 1, true>, a, n, stream, 0);        \
+    return launch_ms(k_multi_step<MM, false, 0, true, DD, true, 1, true>, a, n, stream, 0);                     \
+  } while (0)
 #define OC_MS_SPLIT_BOTH(MM, DD)                   \
+  if (o.policy) OC_MS_POL(MM, DD);                 \
   if (xo && sp == 4) OC_MS_SPLIT(MM, DD, true);    \
   if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, false)
 #else
@@ -2568,6 +2633,9 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
 #endif
 #undef OC_MS
 #undef OC_MS_SPLIT_BOTH
+#ifdef OC_SPECIALIZED
+#undef OC_MS_POL
+#endif
 #undef OC_MS_SPLIT
 #undef OC_MS_X
 }

@@ -72,7 +72,7 @@ def spec_header_text(blob, geometry=True) -> str:
 def _source_digest():
     h = hashlib.sha1()
     inc = os.path.join(_build.CSRC, "..", "..", "include")
-    files = [os.path.join(_build.CSRC, s) for s in _build.SOURCES]
+    files = [os.path.join(_build.CSRC, s) for s in list(_build.SOURCES) + list(_build.LOCAL_HEADERS)]
     files += [os.path.join(inc, f) for f in _build.HEADERS]      # what the source includes
     for f in files:
         with open(f, "rb") as fh:

@@ -297,6 +297,13 @@ class FusedMLPPartner:
         if rc:
             raise _lib.OcError("oc_policy_mlp failed (%d): %s" % (rc, first._L.oc_policy_last_error().decode()))
 
+    def step_policy(self, n):
+        """(w1, w2, b2, rng) device addresses for oc_step_opts.policy (the step kernel evaluates
+        this policy itself; its result lands in ``self.pairs``)."""
+        self._buffers(n)
+        return (self._w[0].data_ptr(), self._w[1].data_ptr(), self._w[2].data_ptr(),
+                self._rng.data_ptr() if self.sample else None)
+
     def pairs_for(self, obs):
         """obs: an ``ObsView`` of the env (``rows`` [F][n], ``timestep``).  Returns int32 [n][2]."""
         FusedMLPPartner.launch([self], [obs.rows], obs.timestep)
@@ -311,11 +318,14 @@ class FusedMLPPartner:
         return self.pairs_for(obs)
 
     def get_state(self, n):
+        """The player's mutable state: its random streams and its pairs (in a one-launch closed
+        loop the pairs are the NEXT step's actions, i.e. state)."""
         self._buffers(n)
-        return self._rng.clone()
+        return self._rng.clone(), self.pairs.clone()
 
     def set_state(self, st):
-        self._rng.copy_(st)
+        self._rng.copy_(st[0])
+        self.pairs.copy_(st[1])
 
 
 class ClosedLoop:
@@ -326,9 +336,25 @@ class ClosedLoop:
     ``venv.ego_action_rows`` before every ``step()``.  ``enqueue()`` issues the launches of one
     step eagerly (what gets captured; also usable inside a caller's own capture)."""
 
-    def __init__(self, venv, ego=None, graph=True, steps=1):
+    def __init__(self, venv, ego=None, graph=True, steps=1, one_launch=None):
         self.venv, self.ego, self.steps = venv, ego, int(steps)
         self.graph = None
+        # ego and partner both FusedMLPPartner: let the step kernel evaluate them (one launch per
+        # step instead of two) where the library can -- a specialised one, at most 4 comm channels --
+        # and where it pays: in a split launch each of the four waves takes one (viewer, half)
+        # pass (7.7 -> 6.7 us per step at 4 096 envs); a lone wave per 64 envs would run all four
+        # passes back to back (9.6 -> 13.7 us at 32 768 envs), so larger batches keep two launches
+        pt = venv.partner
+        can = (isinstance(ego, FusedMLPPartner) and isinstance(pt, FusedMLPPartner) and pt.F == ego.F
+               and pt.C == ego.C and ego.C <= 4 and venv._b.kernel_flavour == "spec")
+        if one_launch and not can:
+            raise ValueError("one_launch needs two FusedMLPPartner of one shape, C <= 4 and a specialised library")
+        self.one_launch = (can and venv._b.launch_waves_per_64 == 4) if one_launch is None else bool(one_launch)
+        self._primed = False
+        if self.one_launch:     # the first step's pairs: one launch of the policy kernel, outside any graph
+            o0, o1 = venv._obs_tensors(0), venv._obs_tensors(1)
+            FusedMLPPartner.launch([ego, pt], [o0.rows, o1.rows], o0.timestep)
+            self._primed = True
         if graph:
             for pl in (ego, venv.partner):
                 if pl is not None and not getattr(pl, "graph_safe", False):
@@ -340,10 +366,19 @@ class ClosedLoop:
         ego, pt = self.ego, v.partner
         if isinstance(ego, FusedMLPPartner):
             if isinstance(pt, FusedMLPPartner) and pt.F == ego.F and pt.C == ego.C:
-                # both policies in ONE launch, their pairs consumed by the step as they lie
                 o0, o1 = v._obs_tensors(0), v._obs_tensors(1)
-                FusedMLPPartner.launch([ego, pt], [o0.rows, o1.rows], o0.timestep)
-                v._b.multi_step(v._act, ego_pairs=ego.pairs, alt_pairs=pt.pairs)
+                if self.one_launch:
+                    # the step kernel evaluates both policies itself, behind the step, on the
+                    # observations it has just written, and leaves the NEXT step's pairs in
+                    # ego.pairs / pt.pairs (oc_step_opts.policy): ONE launch per step.  (The pairs
+                    # of the very first step came from one launch of the policy kernel: __init__.)
+                    n = v.num_envs
+                    v._b.multi_step(v._act, ego_pairs=ego.pairs, alt_pairs=pt.pairs,
+                                    policy=(ego.step_policy(n), pt.step_policy(n)))
+                else:
+                    # both policies in ONE launch, their pairs consumed by the step as they lie
+                    FusedMLPPartner.launch([ego, pt], [o0.rows, o1.rows], o0.timestep)
+                    v._b.multi_step(v._act, ego_pairs=ego.pairs, alt_pairs=pt.pairs)
             else:
                 v._partner_and_step(ego.pairs_for(v._obs_tensors(0)))
         else:
@@ -457,9 +492,9 @@ class OvercookedVecEnv(_VecEnvBase):
         self._version += 1
         return self._obs_tensors(0)
 
-    def closed_loop(self, ego=None, graph=True, steps=1):
+    def closed_loop(self, ego=None, graph=True, steps=1, one_launch=None):
         """ego policy -> partner policy -> fused step as one hipGraph (see ``ClosedLoop``)."""
-        return ClosedLoop(self, ego, graph=graph, steps=steps)
+        return ClosedLoop(self, ego, graph=graph, steps=steps, one_launch=one_launch)
 
     def _fast_plan(self):
         """Addresses for the single-launch path of step_tensors, or False when it does not apply

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 4
+#define OC_ABI_VERSION 5
 #define OC_API __attribute__((visibility("default")))
 
 enum {
@@ -112,7 +112,23 @@ typedef struct {
  *            step's outputs -- state + metrics / shaped reward / viewer 0 / viewer 1.  The library
  *            picks 4 while 4 * n / 64 waves still get a SIMD each (n <= 16 384 on an MI355X:
  *            3.55 -> 3.07 us per step at 4 096 envs) and 1 beyond.  Any other value = 0.
+ *   policy   NULL, or oc_step_policy[2] (HOST array, read at the call): the closed loop in ONE
+ *            launch.  After the step, the kernel itself evaluates both players' MLP policies
+ *            (include/oc_policy.h: the same network, packed weights and arithmetic as oc_policy_mlp)
+ *            on the observations it has just produced -- policy[0] on viewer 0's rows, policy[1]
+ *            on viewer 1's -- and OVERWRITES ego_pairs / alt_pairs with the sampled (move, comm) of
+ *            the NEXT step.  Needs both pair tensors as int32, at most 4 comm channels, and a
+ *            specialised library; in a split launch each of the four waves evaluates one
+ *            (viewer, half of the 64 envs) behind a second barrier.  Results are identical to
+ *            oc_policy_mlp followed by oc_multi_step.
  * `actions` may be NULL when ego_pairs and one of alt_pairs / alt_rng are given. */
+typedef struct {
+  const uint16_t *w1;   /* fp16 fragments, include/oc_policy.h */
+  const uint16_t *w2;
+  const float *b2;
+  uint32_t *rng;        /* uint32 [2][n] PCG32 states (move, comm), or NULL = greedy */
+} oc_step_policy;
+
 typedef struct {
   double *ep_return;
   int32_t *ep_length;
@@ -122,6 +138,7 @@ typedef struct {
   int32_t *alt_played;
   int32_t pairs_int64;
   int32_t waves_per_64;
+  const oc_step_policy *policy;
 } oc_step_opts;
 
 /* metrics accumulated by the step kernels when `metrics` != NULL: a device tensor

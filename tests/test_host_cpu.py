@@ -97,7 +97,7 @@ def test_c_abi_exports_every_declared_symbol():
     L = _lib.load()
     for sym in declared:
         assert getattr(L, sym) is not None
-    assert L.oc_abi_version() == _lib.ABI_VERSION == 4
+    assert L.oc_abi_version() == _lib.ABI_VERSION == 5
     # argument validation happens before any device work
     assert L.oc_step(None, None, None, None, None, None, 0, None, None, None, 0, None) == -1
     assert b"oc_step" in L.oc_last_error()

@@ -108,9 +108,10 @@ def test_samples_follow_the_softmax_and_streams_advance():
 
 
 def test_fused_policies_drive_the_closed_loop():
-    """ego + partner FusedMLPPartner inside OvercookedVecEnv.closed_loop: two launches per step
-    (policies, fused env step); the hipGraph replay equals the eager loop, and what the env
-    executed is what the policies wrote (a twin env stepped with the same pairs)."""
+    """ego + partner FusedMLPPartner inside OvercookedVecEnv.closed_loop, two launches per step
+    (both policies, then the fused env step; `one_launch=False`): the hipGraph replay equals the
+    eager loop, and what the env executed is what the policies wrote (a twin env stepped with the
+    same pairs)."""
     from types import SimpleNamespace
     from gym_comm_amd.vec_env import FusedMLPPartner, MLPPolicy, OvercookedVecEnv
     from gym_comm_amd.batched import BatchedOvercooked
@@ -125,7 +126,7 @@ def test_fused_policies_drive_the_closed_loop():
         alt = FusedMLPPartner(MLPPolicy(S, 2, seed=2).cuda(), sample=True, seed=8)
         venv = OvercookedVecEnv(arg, n, partner=alt, seed=1)
         venv.reset_tensors()
-        return venv, ego, alt, venv.closed_loop(ego, graph=graph, steps=4 if graph else 1)
+        return venv, ego, alt, venv.closed_loop(ego, graph=graph, steps=4 if graph else 1, one_launch=False)
 
     ve, ego_e, alt_e, loop_e = make(False)
     vg, ego_g, alt_g, loop_g = make(True)
@@ -170,3 +171,46 @@ def test_refresh_repacks_in_place_and_a_captured_graph_sees_the_new_weights():
     after = fused.logits.clone()
     assert float((after - _reference_logits(pol, rows, env.timestep)).abs().max()) < 2e-2
     assert float((after - before).abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("n", [1500, 20000], ids=["split-launch", "one-wave-launch"])
+def test_closed_loop_in_one_launch_equals_policy_kernel_plus_step(n):
+    """oc_step_opts.policy: the step kernel evaluates both MLP policies itself, behind the step
+    (a split workgroup: one (viewer, half) pass per wave behind a second barrier; above 16 384
+    envs: the lone wave runs all four passes), and leaves the next step's pairs in place.  Same
+    network, same packed weights, same random streams => bit-identical to one launch of the policy
+    kernel followed by one of the step, eagerly and as a hipGraph."""
+    from types import SimpleNamespace
+    from gym_comm_amd.vec_env import FusedMLPPartner, MLPPolicy, OvercookedVecEnv
+    arg = SimpleNamespace(level="open-divider_tomato", num_agents=2, max_num_timesteps=40, ego_config={},
+                          partner_config={}, num_communication=2, communication_on=True, ego_led=False,
+                          fow_radius=2)
+
+    def make(one_launch, graph):
+        ego = FusedMLPPartner(MLPPolicy(3, 2, seed=1).cuda(), sample=True, seed=7)
+        alt = FusedMLPPartner(MLPPolicy(3, 2, seed=2).cuda(), sample=True, seed=8)
+        venv = OvercookedVecEnv(arg, n, partner=alt, seed=1)
+        venv.reset_tensors()
+        loop = venv.closed_loop(ego, graph=graph, steps=3 if graph else 1, one_launch=one_launch)
+        assert loop.one_launch == one_launch
+        return venv, ego, alt, loop
+
+    two = make(False, False)
+    one = make(True, False)
+    oneg = make(True, True)
+    assert one[0]._b.kernel_flavour == "spec" and one[0]._b.launch_waves_per_64 == (4 if n <= 16384 else 1)
+    executed = []
+    for k in range(9):
+        two[3].step()
+        executed.append((two[1].pairs.clone(), two[2].pairs.clone()))     # what step k executed
+        before = (one[1].pairs.clone(), one[2].pairs.clone())              # what step k is about to execute
+        one[3].step()
+        assert torch.equal(before[0], executed[k][0]) and torch.equal(before[1], executed[k][1]), k
+        for name in ("state", "obs", "shaped_reward", "done", "ep_return", "ep_length", "comm"):
+            assert torch.equal(getattr(two[0]._b, name), getattr(one[0]._b, name)), (k, name)
+        if k % 3 == 2:
+            oneg[3].step()
+            for name in ("state", "obs", "shaped_reward", "done", "ep_return"):
+                assert torch.equal(getattr(oneg[0]._b, name), getattr(one[0]._b, name)), (k, name)
+            assert torch.equal(oneg[1].pairs, one[1].pairs) and torch.equal(oneg[2]._rng, one[2]._rng), k
+    assert two[0]._b.read_metrics()["env_steps"] == one[0]._b.read_metrics()["env_steps"] == 9 * n
