@@ -401,6 +401,24 @@ struct RowsT {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), rsrc, voff, row * rowbytes, AUX);
   }
 };
+// RowsT that also leaves every stored value, as a float, in an LDS image [row - rowbase][64 lanes]:
+// how a split workgroup's observation waves hand a viewer's rows to the waves that evaluate the
+// policies (multi_step_body, POL) without a trip through memory.  OT: 0 int32, 1 int8, 2 float32 bits.
+template <int AUX, int OT>
+struct RowsLdsT : RowsT<AUX> {
+  float *lds;
+  int rowbase, lane;
+  __device__ __forceinline__ RowsLdsT(const RowsT<AUX> &rows, float *lds_, int rowbase_, int lane_)
+      : RowsT<AUX>(rows), lds(lds_), rowbase(rowbase_), lane(lane_) {}
+  __device__ __forceinline__ void st(int row, int v) const {
+    RowsT<AUX>::st(row, v);
+    lds[(row - rowbase) * 64 + lane] = OT == 2 ? __builtin_bit_cast(float, v) : (float)v;
+  }
+  __device__ __forceinline__ void st8(int row, int v) const {
+    RowsT<AUX>::st8(row, v);
+    lds[(row - rowbase) * 64 + lane] = (float)v;
+  }
+};
 using Rows = RowsT<0>;          // loads and default-policy stores
 #ifndef OC_AUX_WT
 #define OC_AUX_WT 16            // sc1; -DOC_AUX_WT=<bits> via OC_HIP_EXTRA_FLAGS to try other store policies
@@ -1588,6 +1606,20 @@ struct MultiArgs {
 // 32 768 envs (every SIMD has a wave of its own by then), slower beyond: split_for().
 constexpr int DUTY_STATE = 1, DUTY_SHAPE = 2, DUTY_OBS0 = 4, DUTY_OBS1 = 8, DUTY_ALL = 15;
 
+// Split launch with the policies fused: both viewers' observation rows of the workgroup's 64 envs
+// as floats, [viewer][row][env], and the timestep -- written by the observation waves, read by all
+// four waves' policy passes behind the second barrier.  (Function templates of their own: ONE LDS
+// array for the four arms of the kernel, which are four instantiations of multi_step_body.)
+template <int ROWS>
+__device__ __forceinline__ float *pol_lds_feat() {
+  __shared__ float a[2 * ROWS * 64];
+  return a;
+}
+__device__ __forceinline__ float *pol_lds_ts() {
+  __shared__ float t[64];
+  return t;
+}
+
 // POL (general variant only): the closed loop in one launch -- behind the step, the wave(s) evaluate
 // both players' MLP policies (oc_policy_device.h) on the observation rows just written and put the
 // NEXT step's (move, comm) pairs where this step read its own (oc_step_opts.policy).  One pass =
@@ -1601,6 +1633,11 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
   constexpr int A = 2;
   constexpr bool D_STATE = (DUTY & DUTY_STATE) != 0, D_SHAPE = (DUTY & DUTY_SHAPE) != 0;
   using Out = RowsT<WT ? AUX_WT : 0>;
+#ifdef OC_SPECIALIZED
+  constexpr int POL_ROWS = (POL && SPLIT) ? 22 + OC_SPEC_HDR.S + 8 : 1;   // F at most: 4 comm channels
+#else
+  constexpr int POL_ROWS = 1;
+#endif
   OC_HDR_LOAD(p);
   // n < 2^31 / (4 * rows): fits_buffer().  Split: one workgroup = SP waves over the same 64 envs.
   const int i = SPLIT ? (int)blockIdx.x * 64 + (int)(threadIdx.x & 63)
@@ -1776,11 +1813,27 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     const int F = 22 + L.S() + 2 * C;
     const bool ego_blind = cfg_blind & 1;
     const Out ob(p.obs, p.n, 2 * F, i, OT == 1 ? 1 : 4);
-    if constexpr ((DUTY & DUTY_OBS0) != 0)
-      env_obs<A, M, DUP, OT>(L, p.R, e, 0, p.cfg.obs.fow_radius, cfg_blind & 1, ego_blind, C, c0, c1, ob, 0);
-    if constexpr ((DUTY & DUTY_OBS1) != 0)
-      env_obs<A, M, DUP, OT>(L, p.R, e, 1, p.cfg.obs.fow_radius, (cfg_blind >> 1) & 1, ego_blind, C, c0, c1, ob, F);
-    if constexpr ((DUTY & DUTY_OBS0) != 0) Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
+    if constexpr (POL && SPLIT) {
+      // (split launch with the policies fused: the rows also go to the LDS image the policy passes read)
+      const int ln = (int)threadIdx.x & 63;
+      if constexpr ((DUTY & DUTY_OBS0) != 0) {
+        const RowsLdsT<WT ? AUX_WT : 0, OT> obl(ob, pol_lds_feat<POL_ROWS>(), 0, ln);
+        env_obs<A, M, DUP, OT>(L, p.R, e, 0, p.cfg.obs.fow_radius, cfg_blind & 1, ego_blind, C, c0, c1, obl, 0);
+        const double tsd = timestep_of(e.t, p.R);
+        Out(p.timestep, p.n, 1, i, 8).st_f64(0, tsd);
+        pol_lds_ts()[ln] = (float)tsd;
+      }
+      if constexpr ((DUTY & DUTY_OBS1) != 0) {
+        const RowsLdsT<WT ? AUX_WT : 0, OT> obl(ob, pol_lds_feat<POL_ROWS>() + POL_ROWS * 64, F, ln);
+        env_obs<A, M, DUP, OT>(L, p.R, e, 1, p.cfg.obs.fow_radius, (cfg_blind >> 1) & 1, ego_blind, C, c0, c1, obl, F);
+      }
+    } else {
+      if constexpr ((DUTY & DUTY_OBS0) != 0)
+        env_obs<A, M, DUP, OT>(L, p.R, e, 0, p.cfg.obs.fow_radius, cfg_blind & 1, ego_blind, C, c0, c1, ob, 0);
+      if constexpr ((DUTY & DUTY_OBS1) != 0)
+        env_obs<A, M, DUP, OT>(L, p.R, e, 1, p.cfg.obs.fow_radius, (cfg_blind >> 1) & 1, ego_blind, C, c0, c1, ob, F);
+      if constexpr ((DUTY & DUTY_OBS0) != 0) Out(p.timestep, p.n, 1, i, 8).st_f64(0, timestep_of(e.t, p.R));
+    }
     OC_STAMP(5);   // observation stores issued
     if constexpr (D_SHAPE) {
       // ... and they drain while the shaping is summed
@@ -1799,8 +1852,9 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
   OC_STAMP(8);
   if constexpr (POL) {
     static_assert(XO, "the fused policies belong to the general variant");
-    // every observation row (and the timestep) of this workgroup's 64 envs is in memory
-    if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // split: every observation row (and the timestep) of this workgroup's 64 envs is in LDS;
+    // a lone wave re-reads its own rows from memory
+    if constexpr (SPLIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int lane = (int)threadIdx.x & 63;
     const int C = p.cfg.obs.num_comm, F = 22 + L.S() + 2 * C;
@@ -1819,8 +1873,15 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
         const uint32_t env = (uint32_t)(ok ? env0 : n_ - 1);
         const void *rows = (const char *)p.obs + (size_t)v * F * n_ * ELEM;
         int32_t *pairs = const_cast<int32_t *>(v == 0 ? p.opt.ego_pairs : p.opt.alt_pairs);
-        ocpol::policy_pass<OT, 4>(rows, n32, env, ok, lane, p.pol[v].w1, p.pol[v].w2, p.pol[v].b2, p.pol[v].rng, pairs,
-                                  nullptr, (float)p.timestep[env], F, C, p.pol_ksteps);
+        if constexpr (SPLIT) {
+          const int col = 32 * q + (lane & 31);
+          ocpol::policy_pass<OT, 4, true>(rows, n32, env, ok, lane, p.pol[v].w1, p.pol[v].w2, p.pol[v].b2,
+                                          p.pol[v].rng, pairs, nullptr, pol_lds_ts()[col], F, C, p.pol_ksteps,
+                                          pol_lds_feat<POL_ROWS>() + v * POL_ROWS * 64, col);
+        } else {
+          ocpol::policy_pass<OT, 4>(rows, n32, env, ok, lane, p.pol[v].w1, p.pol[v].w2, p.pol[v].b2, p.pol[v].rng,
+                                    pairs, nullptr, (float)p.timestep[env], F, C, p.pol_ksteps);
+        }
       }
   }
 #ifdef OC_STAMPS

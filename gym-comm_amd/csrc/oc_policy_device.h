@@ -99,11 +99,13 @@ __device__ __forceinline__ int pick(const f32x16 &v, int count, bool sample, uin
 // works for env `env` (the same for lanes l and l + 32; `valid` false = a lane past the batch,
 // which computes on a clamped env and stores nothing) -- and writes pairs[env][h].
 //   obs: the viewer's rows [F][n]; ts: the env's timestep; rng: uint32 [2][n] or NULL (greedy)
-template <int OT, int CMAX>
+//   LDSSRC: the features come from an LDS image instead -- `lds` float [F][64] (one column per env
+//   of the workgroup), this lane's column `col` -- as the fused step kernel hands them over
+template <int OT, int CMAX, bool LDSSRC = false>
 __device__ __forceinline__ void policy_pass(const void *obs, uint32_t n32, uint32_t env, bool valid, int lane,
                                             const uint16_t *w1_, const uint16_t *w2_, const float *b2_,
                                             uint32_t *rng, int32_t *pairs, float *logits, float ts, int F,
-                                            int C, int ksteps) {
+                                            int C, int ksteps, const float *lds = nullptr, int col = 0) {
   const int h = lane >> 5;
   // ---- H^T = W1aug . X^T ---------------------------------------------------------------
   f32x16 acc0, acc1;
@@ -115,12 +117,14 @@ __device__ __forceinline__ void policy_pass(const void *obs, uint32_t n32, uint3
     const uint32_t k0 = 16 * s + 8 * h, off0 = k0 * n32 + env;   // this lane's first feature of the k-step
     if (16 * s + 16 <= F) {   // uniform: every feature of this k-step is an observation row
 #pragma unroll
-      for (int j = 0; j < 8; j++) b[j] = (_Float16)obs_at<OT>(obs, off0 + (uint32_t)j * n32);
+      for (int j = 0; j < 8; j++)
+        b[j] = (_Float16)(LDSSRC ? lds[(k0 + j) * 64 + col] : obs_at<OT>(obs, off0 + (uint32_t)j * n32));
     } else {
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int k = (int)k0 + j;
-        const float xv = obs_at<OT>(obs, k < F ? off0 + (uint32_t)j * n32 : env);   // (always a readable element)
+        const float xv = LDSSRC ? lds[(k < F ? k : 0) * 64 + col]
+                                : obs_at<OT>(obs, k < F ? off0 + (uint32_t)j * n32 : env);   // (always a readable element)
         b[j] = (_Float16)(k < F ? xv : k == F ? ts : k == F + 1 ? 1.0f : 0.0f);
       }
     }
