@@ -1658,6 +1658,18 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
   MetricsSlot slot(metrics_, i);
   int reward = 0, done = 0, success = 0, comp = 0;
   bool err = false;
+  // (POL, split: which (viewer, half) pass this wave runs behind the step -- viewer 0 / first half
+  // on the OBS0 wave, viewer 1 / first half on OBS1, the second halves on the STATE and SHAPE waves)
+  constexpr int POL_MINE = (DUTY == DUTY_OBS0) ? 0 : (DUTY == DUTY_OBS1) ? 2 : (DUTY == DUTY_STATE) ? 1 : 3;
+  constexpr int POL_VIEWER = POL_MINE >> 1;
+  [[maybe_unused]] ocpol::Weights pol_w;
+  if constexpr (POL && SPLIT) {
+    // This wave's pass is for viewer POL_VIEWER: its share of that player's weights is fetched
+    // now, under the wait for the state -- by EVERY lane: a lane's fragments are rows of the weight
+    // matrices, needed whether or not the lane has an env of its own.
+    ocpol::load_weights(pol_w, p.pol[POL_VIEWER].w1, p.pol[POL_VIEWER].w2, p.pol[POL_VIEWER].b2,
+                        (int)threadIdx.x & 63, p.pol_ksteps);
+  }
   if (valid) {
     constexpr int WS = state_words<A, M, DUP>();
     const Out st(state_, n_, WS, i), cm(comm_, n_, 2, i);
@@ -1864,10 +1876,8 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     for (int v = 0; v < 2; v++)
 #pragma unroll
       for (int q = 0; q < 2; q++) {
-        // a split workgroup: viewer 0 / first half on the OBS0 wave, viewer 1 / first half on OBS1,
-        // the second halves on the STATE and SHAPE waves; a lone wave: all four passes
-        constexpr int mine_split = (DUTY == DUTY_OBS0) ? 0 : (DUTY == DUTY_OBS1) ? 2 : (DUTY == DUTY_STATE) ? 1 : 3;
-        if (SPLIT && (2 * v + q) != mine_split) continue;
+        // a split workgroup: this wave's one pass (POL_MINE); a lone wave: all four
+        if (SPLIT && (2 * v + q) != POL_MINE) continue;
         const int64_t env0 = (int64_t)(i & ~63) + 32 * q + (lane & 31);
         const bool ok = env0 < n_;
         const uint32_t env = (uint32_t)(ok ? env0 : n_ - 1);
@@ -1875,9 +1885,9 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
         int32_t *pairs = const_cast<int32_t *>(v == 0 ? p.opt.ego_pairs : p.opt.alt_pairs);
         if constexpr (SPLIT) {
           const int col = 32 * q + (lane & 31);
-          ocpol::policy_pass<OT, 4, true>(rows, n32, env, ok, lane, p.pol[v].w1, p.pol[v].w2, p.pol[v].b2,
-                                          p.pol[v].rng, pairs, nullptr, pol_lds_ts()[col], F, C, p.pol_ksteps,
-                                          pol_lds_feat<POL_ROWS>() + v * POL_ROWS * 64, col);
+          ocpol::policy_pass<OT, 4, true, true>(rows, n32, env, ok, lane, p.pol[v].w1, p.pol[v].w2, p.pol[v].b2,
+                                                p.pol[v].rng, pairs, nullptr, pol_lds_ts()[col], F, C, p.pol_ksteps,
+                                                pol_lds_feat<POL_ROWS>() + v * POL_ROWS * 64, col, &pol_w);
         } else {
           ocpol::policy_pass<OT, 4>(rows, n32, env, ok, lane, p.pol[v].w1, p.pol[v].w2, p.pol[v].b2, p.pol[v].rng,
                                     pairs, nullptr, (float)p.timestep[env], F, C, p.pol_ksteps);
@@ -2622,6 +2632,8 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
       a.pol[k] = o.policy[k];
     }
     a.pol_ksteps = (22 + lv->hdr.S + 2 * cfg->obs.num_comm + 2 + 15) / 16;
+    if (a.pol_ksteps > 3)
+      return fail(OC_E_BADARG, "oc_multi_step: opts.policy handles at most 46 observation rows; use oc_policy_mlp");
     a.opt.policy = nullptr;   // (a host pointer: nothing on the device may look at it)
   }
   const size_t lds = (size_t)lv->n16 * 16;

@@ -95,24 +95,51 @@ __device__ __forceinline__ int pick(const f32x16 &v, int count, bool sample, uin
   return arg;
 }
 
+// A lane's share of one player's packed weights (include/oc_policy.h): the A fragments of both
+// products and the second product's start value -- 14 x 16 bytes.  The policy kernel loads them
+// where it needs them; the fused step kernel loads them at its start, under the wait for the
+// env state, so that the pass behind the step finds them in registers.
+constexpr int MAX_KSTEPS = 3;   // F + 2 <= 48 features (the fused step: C <= 4, S <= 14)
+struct Weights {
+  half8 w1[2][MAX_KSTEPS];
+  half8 w2[4];
+  float4 b2[4];
+};
+__device__ __forceinline__ void load_weights(Weights &w, const uint16_t *w1_, const uint16_t *w2_,
+                                             const float *b2_, int lane, int ksteps) {
+  const half8 *w1 = (const half8 *)w1_, *w2 = (const half8 *)w2_;
+#pragma unroll
+  for (int s = 0; s < MAX_KSTEPS; s++)
+    if (s < ksteps) {   // uniform
+      w.w1[0][s] = w1[(size_t)(0 * ksteps + s) * 64 + lane];
+      w.w1[1][s] = w1[(size_t)(1 * ksteps + s) * 64 + lane];
+    }
+#pragma unroll
+  for (int s = 0; s < 4; s++) w.w2[s] = w2[s * 64 + lane];
+#pragma unroll
+  for (int q = 0; q < 4; q++) w.b2[q] = ((const float4 *)b2_ + lane * 4)[q];
+}
+
 // One pass: the calling wave evaluates the network for 32 envs -- lane l (r = l & 31, h = l >> 5)
 // works for env `env` (the same for lanes l and l + 32; `valid` false = a lane past the batch,
 // which computes on a clamped env and stores nothing) -- and writes pairs[env][h].
 //   obs: the viewer's rows [F][n]; ts: the env's timestep; rng: uint32 [2][n] or NULL (greedy)
 //   LDSSRC: the features come from an LDS image instead -- `lds` float [F][64] (one column per env
 //   of the workgroup), this lane's column `col` -- as the fused step kernel hands them over
-template <int OT, int CMAX, bool LDSSRC = false>
+//   PRE: the weights are already in registers (`pre`, load_weights), ksteps <= MAX_KSTEPS
+template <int OT, int CMAX, bool LDSSRC = false, bool PRE = false>
 __device__ __forceinline__ void policy_pass(const void *obs, uint32_t n32, uint32_t env, bool valid, int lane,
                                             const uint16_t *w1_, const uint16_t *w2_, const float *b2_,
                                             uint32_t *rng, int32_t *pairs, float *logits, float ts, int F,
-                                            int C, int ksteps, const float *lds = nullptr, int col = 0) {
+                                            int C, int ksteps, const float *lds = nullptr, int col = 0,
+                                            const Weights *pre = nullptr) {
   const int h = lane >> 5;
   // ---- H^T = W1aug . X^T ---------------------------------------------------------------
   f32x16 acc0, acc1;
 #pragma unroll
   for (int q = 0; q < 16; q++) acc0[q] = 0.0f, acc1[q] = 0.0f;
   const half8 *w1 = (const half8 *)w1_;
-  for (int s = 0; s < ksteps; s++) {
+  auto kstep = [&](int s, const half8 &a0, const half8 &a1) {
     half8 b;
     const uint32_t k0 = 16 * s + 8 * h, off0 = k0 * n32 + env;   // this lane's first feature of the k-step
     if (16 * s + 16 <= F) {   // uniform: every feature of this k-step is an observation row
@@ -128,10 +155,16 @@ __device__ __forceinline__ void policy_pass(const void *obs, uint32_t n32, uint3
         b[j] = (_Float16)(k < F ? xv : k == F ? ts : k == F + 1 ? 1.0f : 0.0f);
       }
     }
-    const half8 a0 = w1[(size_t)(0 * ksteps + s) * 64 + lane];
-    const half8 a1 = w1[(size_t)(1 * ksteps + s) * 64 + lane];
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, acc1, 0, 0, 0);
+  };
+  if constexpr (PRE) {
+#pragma unroll
+    for (int s = 0; s < MAX_KSTEPS; s++)
+      if (s < ksteps) kstep(s, pre->w1[0][s], pre->w1[1][s]);   // uniform; static register indices
+  } else {
+    for (int s = 0; s < ksteps; s++)
+      kstep(s, w1[(size_t)(0 * ksteps + s) * 64 + lane], w1[(size_t)(1 * ksteps + s) * 64 + lane]);
   }
 
   // ---- log2(e) L^T = W2' . r + b2'  (see sigmoid_complement) -----------------------------
@@ -140,7 +173,7 @@ __device__ __forceinline__ void policy_pass(const void *obs, uint32_t n32, uint3
     const float4 *b2 = (const float4 *)b2_ + lane * 4;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const float4 v = b2[q];
+      const float4 v = PRE ? pre->b2[q] : b2[q];
       out[4 * q + 0] = v.x, out[4 * q + 1] = v.y, out[4 * q + 2] = v.z, out[4 * q + 3] = v.w;
     }
   }
@@ -153,7 +186,7 @@ __device__ __forceinline__ void policy_pass(const void *obs, uint32_t n32, uint3
       const float av = (s >> 1) ? acc1[8 * (s & 1) + j] : acc0[8 * (s & 1) + j];
       b[j] = (_Float16)sigmoid_complement(av);
     }
-    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s * 64 + lane], b, out, 0, 0, 0);
+    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(PRE ? pre->w2[s] : w2[s * 64 + lane], b, out, 0, 0, 0);
   }
 
   // ---- sample and store ------------------------------------------------------------------
