@@ -120,6 +120,8 @@ class BatchedOvercooked:
         self._layout = obs_layout(self.S, self.C)
         self._ms_args = None
         self._policy_arr = None
+        self._arena_pinned = None
+        self._fetch_plan = None
         # random-* levels: item start cells differ per env and per episode
         self.placement = None
         self.rng = None
@@ -345,11 +347,18 @@ class BatchedOvercooked:
         """ONE device->host copy of everything a step produced: returns {name: numpy view}
         for state, reward, done, shaping, comm, obs, timestep, shaped_reward (host copies
         with the device tensors' shapes and dtypes).  Synchronises with the stream."""
-        host = self._arena.cpu().numpy()
-        out = {}
-        for name, (o, nb, shape, dt) in self._arena_layout.items():
-            out[name] = host[o:o + nb].view(getattr(np, str(dt).replace("torch.", ""))).reshape(shape)
-        return out
+        # through a pinned staging buffer (an asynchronous copy + one stream sync: about half the
+        # latency of a pageable .cpu() for the single-env adapter's 1 KB arena), then a host copy
+        # so that the caller owns what it gets
+        if self._arena_pinned is None:
+            self._arena_pinned = torch.empty(self._arena.numel(), dtype=torch.uint8, pin_memory=True)
+        self._arena_pinned.copy_(self._arena, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        host = self._arena_pinned.numpy().copy()
+        if self._fetch_plan is None:
+            self._fetch_plan = [(name, o, o + nb, np.dtype(str(dt).replace("torch.", "")), shape)
+                                for name, (o, nb, shape, dt) in self._arena_layout.items()]
+        return {name: host[lo:hi].view(ndt).reshape(shape) for name, lo, hi, ndt, shape in self._fetch_plan}
 
     def metrics_vector(self):
         """int64[8] totals (sum over the per-wave slots), on the device; None when the env was

@@ -592,14 +592,14 @@ def _make_multi_env_class():
             """obs [2][F][1], ts [1]: device tensors or their host copies (BatchedOvercooked.fetch)."""
             if isinstance(obs, torch.Tensor):
                 obs, ts = obs.cpu().numpy(), ts.cpu().numpy()
-            o = obs[:, :, 0].astype(np.int64)
+            o = obs[:, :, 0].astype(np.int64)       # a fresh array per call: the keys are views of it
             t = ts
             ego_blind = bool(self._b.ego_config["BLIND"])
             out = []
             for v in range(2):
                 d = {"timestep": np.array((t[0],))}
                 for k, (a, b) in self._layout.items():
-                    d[k] = o[v, a:b].copy()
+                    d[k] = o[v, a:b]
                 if not ego_blind:                       # bool pair unless the EGO is BLIND (:154)
                     d["agent_is_holding"] = d["agent_is_holding"].astype(bool)
                 d["agent1_comm"] = d["agent1_comm"].astype(np.float64)
