@@ -3,6 +3,8 @@ fp32 evaluation of the same network.  Not part of the environment's semantics (n
 tolerance is that of fp16 operands with fp32 accumulation -- logits within 2e-2 -- and the
 sampled / greedy actions are checked through properties (greedy = argmax wherever the fp32 gap is
 clear; sample frequencies = softmax; streams advance; ragged batches; every observation type)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -198,7 +200,9 @@ def test_closed_loop_in_one_launch_equals_policy_kernel_plus_step(n):
     two = make(False, False)
     one = make(True, False)
     oneg = make(True, True)
-    assert one[0]._b.kernel_flavour == "spec" and one[0]._b.launch_waves_per_64 == (4 if n <= 16384 else 1)
+    assert one[0]._b.kernel_flavour == "spec"
+    if "OC_SPLIT" not in os.environ:        # (a forced launch mode runs both cases the same way)
+        assert one[0]._b.launch_waves_per_64 == (4 if n <= 16384 else 1)
     executed = []
     for k in range(9):
         two[3].step()
