@@ -14,6 +14,12 @@ from gym_comm_amd.vec_env import OvercookedVecEnv, RandomPartner
 
 
 def timed(fn, steps):
+    # >= 150 ms of continuous work first: the first tens of ms after host-side idling can run 10x
+    # slow on this box (tools/slow_replay_probe.py)
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.15:
+        fn(k)
+        k += 1
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
