@@ -24,7 +24,9 @@ barrier + synchronize on both sides.  Blocks are hipGraph replays; a K shorter t
 ~10 us between two graph launches is not charged to 20 steps.  A HIP event on the launch
 stream separates the replays; ``ms_per_step`` is the MEDIAN block time / K (MAX over ranks):
 a short ``--steps`` gives the steady-state number, not one launch + sync latency.  The wall
-clock over the whole region is reported beside it (``ms_per_step_wall``).
+clock over the whole region is reported beside it (``ms_per_step_wall``).  Before the calibration
+and the timed region, 150 ms of untimed replays (on top of the ``--warmup`` steps) let the box
+settle: the first tens of ms of GPU work after host-side idling can run ~10x slow here.
 
 ``--mode closed-loop`` measures the same kernel with policies in the loop (an ego and a
 partner MLP on the observations, actions sampled on the device, episode statistics; one
@@ -53,6 +55,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WINDOW = 256                # pre-generated action steps, cycled
 MIN_TIMED_MS = 50.0         # GPU time the timed region must cover (reps is derived from it)
+SETTLE_MS = 150.0        # untimed replays before calibration and timing (see main)
 ELEM = {"int32": 4, "int8": 1, "float32": 4}
 
 
@@ -343,6 +346,15 @@ def main():
         blocks.prepare((args.warmup, SB))
         blocks.run(args.warmup)
         stream.synchronize()
+        # settle: on this box the first tens of milliseconds of GPU work after host-side idling
+        # (building the batch, capturing the graphs) can run ~10x slow (a clock / power ramp by its
+        # behaviour; tools/slow_replay_probe.py).  SETTLE_MS of untimed replays
+        # -- on top of the `--warmup` steps -- keep that transient out of the calibration and of
+        # the timed region.
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < SETTLE_MS:
+            blocks.run(SB)
+            stream.synchronize()
 
         # reps: enough blocks for MIN_TIMED_MS of GPU time, from a short calibration
         if args.reps > 0:
@@ -459,7 +471,7 @@ def main():
             "timing": {"what": "median over back-to-back blocks of `steps` steps (`reps` of them, "
                                "`blocks_per_replay` per hipGraph replay), HIP events on the launch stream "
                                "between replays, MAX over ranks",
-                       "blocks_per_replay": bpr, "replays": replays,
+                       "blocks_per_replay": bpr, "replays": replays, "settle_ms_untimed": SETTLE_MS,
                        "block_ms_min": block_s[0] * 1e3, "block_ms_median": med_block_s * 1e3,
                        "block_ms_max": block_s[-1] * 1e3, "region_wall_s": wall},
             "rollout_metrics": {"env_steps": m[0], "episodes": m[1], "successes": m[2],
