@@ -175,8 +175,12 @@ def test_refresh_repacks_in_place_and_a_captured_graph_sees_the_new_weights():
     assert float((after - before).abs().max()) > 0.1
 
 
+@pytest.mark.parametrize("level,C,odt", [("open-divider_tomato", 2, torch.int32),
+                                         ("full-divider_salad", 4, torch.int8),      # 39 rows: three k-steps
+                                         ("open-divider_tl", 3, torch.float32)],
+                         ids=["tomato-c2-int32", "salad-c4-int8", "tl-c3-float32"])
 @pytest.mark.parametrize("n", [1500, 20000], ids=["split-launch", "one-wave-launch"])
-def test_closed_loop_in_one_launch_equals_policy_kernel_plus_step(n):
+def test_closed_loop_in_one_launch_equals_policy_kernel_plus_step(n, level, C, odt):
     """oc_step_opts.policy: the step kernel evaluates both MLP policies itself, behind the step
     (a split workgroup: one (viewer, half) pass per wave behind a second barrier; above 16 384
     envs: the lone wave runs all four passes), and leaves the next step's pairs in place.  Same
@@ -184,14 +188,15 @@ def test_closed_loop_in_one_launch_equals_policy_kernel_plus_step(n):
     kernel followed by one of the step, eagerly and as a hipGraph."""
     from types import SimpleNamespace
     from gym_comm_amd.vec_env import FusedMLPPartner, MLPPolicy, OvercookedVecEnv
-    arg = SimpleNamespace(level="open-divider_tomato", num_agents=2, max_num_timesteps=40, ego_config={},
-                          partner_config={}, num_communication=2, communication_on=True, ego_led=False,
+    arg = SimpleNamespace(level=level, num_agents=2, max_num_timesteps=40, ego_config={},
+                          partner_config={}, num_communication=C, communication_on=True, ego_led=False,
                           fow_radius=2)
 
     def make(one_launch, graph):
-        ego = FusedMLPPartner(MLPPolicy(3, 2, seed=1).cuda(), sample=True, seed=7)
-        alt = FusedMLPPartner(MLPPolicy(3, 2, seed=2).cuda(), sample=True, seed=8)
-        venv = OvercookedVecEnv(arg, n, partner=alt, seed=1)
+        venv = OvercookedVecEnv(arg, n, seed=1, obs_dtype=odt)
+        S = venv._b.S
+        ego = FusedMLPPartner(MLPPolicy(S, C, seed=1).cuda(), sample=True, seed=7)
+        venv.partner = alt = FusedMLPPartner(MLPPolicy(S, C, seed=2).cuda(), sample=True, seed=8)
         venv.reset_tensors()
         loop = venv.closed_loop(ego, graph=graph, steps=3 if graph else 1, one_launch=one_launch)
         assert loop.one_launch == one_launch
