@@ -115,9 +115,9 @@ def parse(argv=None):
     p.add_argument("--closed-loop-launches", default="auto", choices=["auto", "1", "2"],
                    help="closed-loop, --policy fused: launches per step -- 1 = the step kernel evaluates both "
                         "policies itself (oc_step_opts.policy), 2 = policy kernel + step; auto = 1 where possible")
-    p.add_argument("--waves-per-64", type=int, default=0, choices=[0, 1, 4],
-                   help="launch hint of the fused step: 0 = the library decides (split launch up to 16384 envs), "
-                        "1 = one wave per 64 envs, 4 = split launch (include/oc_hip.h, oc_step_opts)")
+    p.add_argument("--waves-per-64", type=int, default=0, choices=[0, 1, 2, 4],
+                   help="launch hint of the fused step: 0 = the library decides (four waves per 64 envs up to 24576 envs, two up to 32768), "
+                        "1 = one wave per 64 envs, 2 / 4 = split launches (include/oc_hip.h, oc_step_opts)")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -69,8 +69,8 @@ class BatchedOvercooked:
         self.auto_reset = bool(auto_reset)
         # launch hint of the fused step (include/oc_hip.h, oc_step_opts.waves_per_64): 0 = the
         # library decides, 1 = one wave per 64 envs, 4 = split launch; results are identical
-        if waves_per_64 not in (0, 1, 4):
-            raise ValueError("waves_per_64 must be 0 (auto), 1 or 4")
+        if waves_per_64 not in (0, 1, 2, 4):
+            raise ValueError("waves_per_64 must be 0 (auto), 1, 2 or 4")
         self.waves_per_64 = int(waves_per_64)
         blob = np.ascontiguousarray(lv.blob, dtype=np.int32)
         # per-level specialised kernels when available (specialize.py), else the generic library

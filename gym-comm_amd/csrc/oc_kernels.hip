@@ -1917,7 +1917,8 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
                                                     int32_t *const comm_, int64_t *const metrics_,
                                                     const int64_t n_, const int32_t block_,
                                                     const MultiArgs p) {
-  static_assert(SP == 1 || SP == 4, "waves per 64 envs");
+  static_assert(SP == 1 || SP == 2 || SP == 4, "waves per 64 envs");
+  static_assert(SP != 2 || !POL, "the fused policies need the four-wave split");
   static_assert(SP == 1 || !LDS, "the split launch reads the tables from global memory");
 #ifdef OC_SPECIALIZED
   const MultiArgs &pk = p;
@@ -1939,10 +1940,15 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     multi_step_body<M, LDS, OT, WT, DUP, XO, DUTY_ALL, false, POL>(state_, actions_, comm_, metrics_, n_, block_, p);
   } else {
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if (role == 0) OC_BODY(DUTY_STATE);
-    else if (role == 1) OC_BODY(DUTY_SHAPE);
-    else if (role == 2) OC_BODY(DUTY_OBS0);
-    else OC_BODY(DUTY_OBS1);
+    if constexpr (SP == 2) {   // two waves per 64 envs: state + viewer 0 | shaping + viewer 1
+      if (role == 0) OC_BODY(DUTY_STATE | DUTY_OBS0);
+      else OC_BODY(DUTY_SHAPE | DUTY_OBS1);
+    } else {
+      if (role == 0) OC_BODY(DUTY_STATE);
+      else if (role == 1) OC_BODY(DUTY_SHAPE);
+      else if (role == 2) OC_BODY(DUTY_OBS0);
+      else OC_BODY(DUTY_OBS1);
+    }
   }
 #undef OC_BODY
 }
@@ -2017,17 +2023,24 @@ int launch_ms_split(K kernel, int sp, const MultiArgs &a, int64_t n, void *strea
   return OC_OK;
 }
 
-// Waves per 64 envs for the fused step (see multi_step_body): four while that still leaves every
-// wave a SIMD of its own -- 4 * n / 64 <= 1 024 SIMDs (256 CUs x 4), i.e. n <= 16 384 on an MI355X.
-// tools/split_sweep.sh, tomato-2, us per step, one wave / four waves per 64 envs:
-//   n = 64 3.26 / 2.97, 1 024 3.55 / 3.03, 4 096 3.55 / 3.07, 8 192 3.74 / 3.10, 16 384 3.83 / 3.24,
-//   32 768 4.01 / 3.99, 65 536 5.35 / 5.50, 131 072 7.99 / 12.3.
-// The caller's hint (oc_step_opts.waves_per_64 = 1 / 4) and OC_SPLIT=1/4 (tuning) override.
+// Waves per 64 envs for the fused step (see multi_step_body).  Four while every wave still gets a
+// SIMD of its own -- 4 * n / 64 <= 1 024 SIMDs (256 CUs x 4), i.e. n <= 16 384 on an MI355X -- and a
+// little beyond (up to 24 576 envs: 1.5 waves per SIMD); two (state + viewer 0 | shaping +
+// viewer 1: one wave per SIMD again) up to 32 768; one beyond.
+// tools/split_sweep.sh, us per step, one / two / four waves per 64 envs:
+//   tomato-2  n = 64 3.26 / - / 2.97, 4 096 3.55 / 3.26 / 3.07, 16 384 3.83 / 3.42 / 3.24,
+//             24 576 3.98 / 3.86 / 3.67, 28 672 4.03 / 3.94 / 3.79, 32 768 4.05 / 4.11 / 3.93,
+//             49 152 4.34 / 4.57 / 4.62, 65 536 5.35 / 5.51 / 5.44, 131 072 7.99 / 8.18 / 12.3
+//   salad-2   24 576 4.26 / 3.89 / 4.00, 28 672 4.30 / 4.00 / 4.14, 32 768 4.34 / 4.15 / 4.46,
+//             49 152 4.80 / 4.88 / 4.95;   tl-2  28 672 4.32 / 3.89 / 3.77, 32 768 4.34 / 4.09 / 4.17
+// (between 24 576 and 32 768 envs two waves win on three of the four levels measured and lose
+// 1.7 % on the fourth.)
+// The caller's hint (oc_step_opts.waves_per_64 = 1 / 2 / 4) and OC_SPLIT=1/2/4 (tuning) override.
 int split_for(int64_t n, int hint) {
   static const int forced = getenv("OC_SPLIT") ? atoi(getenv("OC_SPLIT")) : 0;
-  if (forced == 1 || forced == 4) return forced;
-  if (hint == 1 || hint == 4) return hint;
-  return n <= 16384 ? 4 : 1;
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  if (hint == 1 || hint == 2 || hint == 4) return hint;
+  return n <= 24576 ? 4 : n <= 32768 ? 2 : 1;
 }
 
 // The same for the base step (k_step<..., SP = 2>: state wave + shaping wave).  OC_STEP_SPLIT=1/2
@@ -2663,6 +2676,12 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
     return launch_ms_split(k_multi_step<MM, false, 0, true, DD, XX, 4>, 4, a, n, stream);                 \
   } while (0)
 // (the generic library splits the plain variant only: its build time)
+#define OC_MS_SPLIT2(MM, DD)                                                                                 \
+  do {                                                                                                       \
+    if (ot == 1) return launch_ms_split(k_multi_step<MM, false, 1, true, DD, false, 2>, 2, a, n, stream);    \
+    if (ot == 2) return launch_ms_split(k_multi_step<MM, false, 2, true, DD, false, 2>, 2, a, n, stream);    \
+    return launch_ms_split(k_multi_step<MM, false, 0, true, DD, false, 2>, 2, a, n, stream);                 \
+  } while (0)
 #ifdef OC_SPECIALIZED
 // general variant + both policies evaluated behind the step (oc_step_opts.policy)
 #define OC_MS_POL(MM, DD)                                                                                       \
@@ -2680,7 +2699,8 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
 #define OC_MS_SPLIT_BOTH(MM, DD)                   \
   if (o.policy) OC_MS_POL(MM, DD);                 \
   if (xo && sp == 4) OC_MS_SPLIT(MM, DD, true);    \
-  if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, false)
+  if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, false);  \
+  if (!xo && sp == 2) OC_MS_SPLIT2(MM, DD)
 #else
 #define OC_MS_SPLIT_BOTH(MM, DD) if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, false)
 #endif

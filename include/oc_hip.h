@@ -109,9 +109,10 @@ typedef struct {
  *   waves_per_64  launch hint, not semantics (results are identical): 0 = the library decides,
  *            1 = one wave computes the whole step of its 64 envs, 4 = "split launch": four waves
  *            per 64 envs (one workgroup = the four SIMDs of a CU), each producing one of the
- *            step's outputs -- state + metrics / shaped reward / viewer 0 / viewer 1.  The library
- *            picks 4 while 4 * n / 64 waves still get a SIMD each (n <= 16 384 on an MI355X:
- *            3.55 -> 3.07 us per step at 4 096 envs) and 1 beyond.  Any other value = 0.
+ *            step's outputs -- state + metrics / shaped reward / viewer 0 / viewer 1; 2 = two
+ *            waves (state + viewer 0 / shaping + viewer 1).  The library picks 4 up to 24 576
+ *            envs (3.55 -> 3.07 us per step at 4 096 envs on an MI355X), 2 up to 32 768, 1 beyond.
+ *            Any other value = 0.
  *   policy   NULL, or oc_step_policy[2] (HOST array, read at the call): the closed loop in ONE
  *            launch.  After the step, the kernel itself evaluates both players' MLP policies
  *            (include/oc_policy.h: the same network, packed weights and arithmetic as oc_policy_mlp)
@@ -255,7 +256,8 @@ OC_API int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, co
                   int64_t n, void *stream);
 
 /* Waves per 64 envs oc_multi_step will launch for a batch of n envs given the caller's hint
- * (oc_step_opts.waves_per_64): 1 or 4.  Host only; for reports and tests. */
+ * (oc_step_opts.waves_per_64): 1, 2 or 4 (the plain variant; the general one splits four ways or
+ * not at all).  Host only; for reports and tests. */
 OC_API int32_t oc_multi_step_waves(int64_t n, int32_t hint);
 
 /* Uniform random (move, comm) indices for one player of every env, written straight into two

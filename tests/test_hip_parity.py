@@ -87,12 +87,13 @@ def _wrap_env(st, lv, n, **kw):
                 ego_agent_idx=st["ego_agent_idx"], **kw)
 
 
-@pytest.mark.parametrize("fused", [4, 1, 0], ids=["fused-split", "fused-1wave", "step+obs"])
+@pytest.mark.parametrize("fused", [4, 2, 1, 0], ids=["fused-split", "fused-split2", "fused-1wave", "step+obs"])
 @pytest.mark.parametrize("run", WRAP_RUNS, ids=[_rid(r) for r in WRAP_RUNS])
 def test_wrapper_matches_reference_golden(run, fused):
     """OvercookedMultiEnv.multi_step / multi_reset / get_observation2 tapes, through the
-    fused oc_multi_step kernel -- as a split launch (four waves per 64 envs, one output each) and
-    with one wave computing the whole step -- and through oc_step + oc_obs."""
+    fused oc_multi_step kernel -- as a split launch (four waves per 64 envs, one output each; two
+    waves, two outputs each) and with one wave computing the whole step -- and through oc_step +
+    oc_obs."""
     path, spec = run
     z, st = load_golden(path)
     lv = compile_for(st)
@@ -187,7 +188,7 @@ def test_step_matches_oracle_seeded(level, A, T, spec, waves, oracle_lib, monkey
     assert tot_d > 0 and tot_r > 0
 
 
-@pytest.mark.parametrize("waves", [4, 1], ids=["split", "1wave"])
+@pytest.mark.parametrize("waves", [4, 2, 1], ids=["split", "split2", "1wave"])
 @pytest.mark.parametrize("spec", [False, True, "structure"], ids=["generic", "spec", "structure"])
 @pytest.mark.parametrize("level,T,C,radius", [("open-divider_tomato", 100, 2, 2),
                                               ("full-divider_salad", 120, 5, 1),

@@ -104,10 +104,12 @@ def test_c_abi_exports_every_declared_symbol():
     bad = np.zeros(32, np.int32)
     h = ctypes.c_void_p()
     assert L.oc_level_create(bad.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 32, ctypes.byref(h)) == -1
-    # launch policy of the fused step (host only): four waves per 64 envs while each still gets a
-    # SIMD of its own (n <= 16384 on an MI355X), one beyond; the caller's hint overrides
+    # launch policy of the fused step (host only): four waves per 64 envs up to 24576 envs, two up
+    # to 32768, one beyond; the caller's hint overrides
     if "OC_SPLIT" not in os.environ:
-        assert [L.oc_multi_step_waves(n, 0) for n in (1, 4096, 16384, 16385, 131072)] == [4, 4, 4, 1, 1]
+        assert [L.oc_multi_step_waves(n, 0) for n in (1, 4096, 24576, 24577, 32768, 32769, 131072)] == \
+            [4, 4, 4, 2, 2, 1, 1]
+        assert L.oc_multi_step_waves(4096, 2) == 2
         assert L.oc_multi_step_waves(4096, 1) == 1 and L.oc_multi_step_waves(131072, 4) == 4
         assert L.oc_multi_step_waves(4096, 7) == 4 and L.oc_multi_step_waves(131072, -3) == 1
 

@@ -179,10 +179,10 @@ def test_refresh_repacks_in_place_and_a_captured_graph_sees_the_new_weights():
                                          ("full-divider_salad", 4, torch.int8),      # 39 rows: three k-steps
                                          ("open-divider_tl", 3, torch.float32)],
                          ids=["tomato-c2-int32", "salad-c4-int8", "tl-c3-float32"])
-@pytest.mark.parametrize("n", [1500, 20000], ids=["split-launch", "one-wave-launch"])
+@pytest.mark.parametrize("n", [1500, 40000], ids=["split-launch", "one-wave-launch"])
 def test_closed_loop_in_one_launch_equals_policy_kernel_plus_step(n, level, C, odt):
     """oc_step_opts.policy: the step kernel evaluates both MLP policies itself, behind the step
-    (a split workgroup: one (viewer, half) pass per wave behind a second barrier; above 16 384
+    (a split workgroup: one (viewer, half) pass per wave behind a second barrier; at 40 000
     envs: the lone wave runs all four passes), and leaves the next step's pairs in place.  Same
     network, same packed weights, same random streams => bit-identical to one launch of the policy
     kernel followed by one of the step, eagerly and as a hipGraph."""
@@ -207,7 +207,7 @@ def test_closed_loop_in_one_launch_equals_policy_kernel_plus_step(n, level, C, o
     oneg = make(True, True)
     assert one[0]._b.kernel_flavour == "spec"
     if "OC_SPLIT" not in os.environ:        # (a forced launch mode runs both cases the same way)
-        assert one[0]._b.launch_waves_per_64 == (4 if n <= 16384 else 1)
+        assert one[0]._b.launch_waves_per_64 == (4 if n <= 24576 else 1)
     executed = []
     for k in range(9):
         two[3].step()
