@@ -1629,7 +1629,8 @@ __device__ __forceinline__ float *pol_lds_ts() {
 template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int DUTY, bool SPLIT, bool POL = false>
 __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int32_t *const actions_,
                                                 int32_t *const comm_, int64_t *const metrics_,
-                                                const int64_t n_, const int32_t block_, const MultiArgs &p) {
+                                                const int64_t n_, const int32_t block_, const void *const ego_src_,
+                                                const void *const alt_src_, const MultiArgs &p) {
   constexpr int A = 2;
   constexpr bool D_STATE = (DUTY & DUTY_STATE) != 0, D_SHAPE = (DUTY & DUTY_SHAPE) != 0;
   using Out = RowsT<WT ? AUX_WT : 0>;
@@ -1684,11 +1685,11 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     int ego_mv, ego_cm, alt_mv, alt_cm;
     typedef int v4i __attribute__((ext_vector_type(4)));
     if (ego_from_pairs && pairs64) {   // int64 pairs (a torch argmax / sample as it comes): the low words
-      const Rows pr(p.opt.ego_pairs, n_, 1, i, 16);
+      const Rows pr(ego_src_, n_, 1, i, 16);
       const v4i q = (v4i)__builtin_amdgcn_raw_buffer_load_b128(pr.rsrc, pr.voff, 0, 0);
       ego_mv = (q.y == (q.x >> 31)) ? q.x : -1, ego_cm = (q.w == (q.z >> 31)) ? q.z : -1;   // outside int32: invalid
     } else if (ego_from_pairs) {
-      const Rows pr(p.opt.ego_pairs, n_, 1, i, 8);
+      const Rows pr(ego_src_, n_, 1, i, 8);
       const v2i q = (v2i)__builtin_amdgcn_raw_buffer_load_b64(pr.rsrc, pr.voff, 0, 0);
       ego_mv = q.x, ego_cm = q.y;
     } else {
@@ -1697,11 +1698,11 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     }
     uint32_t alt_rs = 0;
     if (alt_from_rng) {
-      alt_rs = (uint32_t)Rows(p.opt.alt_rng, n_, 1, i).ld(0);
+      alt_rs = (uint32_t)Rows(alt_src_, n_, 1, i).ld(0);
       alt_mv = (int)__umulhi(pcg32(alt_rs), 4u);
       alt_cm = (int)__umulhi(pcg32(alt_rs), (uint32_t)p.cfg.obs.num_comm);
       if constexpr (!SPLIT) {   // (split: stored behind the barrier, by the wave that owns the state)
-        Rows(p.opt.alt_rng, n_, 1, i).st(0, (int)alt_rs);
+        Rows(alt_src_, n_, 1, i).st(0, (int)alt_rs);
         if (p.opt.alt_played != nullptr) {
           const Rows ap(p.opt.alt_played, n_, 2, i);
           ap.st(0, alt_mv);
@@ -1709,11 +1710,11 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
         }
       }
     } else if (alt_from_pairs && pairs64) {
-      const Rows pr(p.opt.alt_pairs, n_, 1, i, 16);
+      const Rows pr(alt_src_, n_, 1, i, 16);
       const v4i q = (v4i)__builtin_amdgcn_raw_buffer_load_b128(pr.rsrc, pr.voff, 0, 0);
       alt_mv = (q.y == (q.x >> 31)) ? q.x : -1, alt_cm = (q.w == (q.z >> 31)) ? q.z : -1;
     } else if (alt_from_pairs) {
-      const Rows pr(p.opt.alt_pairs, n_, 1, i, 8);
+      const Rows pr(alt_src_, n_, 1, i, 8);
       const v2i q = (v2i)__builtin_amdgcn_raw_buffer_load_b64(pr.rsrc, pr.voff, 0, 0);
       alt_mv = q.x, alt_cm = q.y;
     } else {
@@ -1754,7 +1755,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       if constexpr (D_STATE) {
         if (alt_from_rng) {
-          Rows(p.opt.alt_rng, n_, 1, i).st(0, (int)alt_rs);
+          Rows(alt_src_, n_, 1, i).st(0, (int)alt_rs);
           if (p.opt.alt_played != nullptr) {
             const Rows ap(p.opt.alt_played, n_, 2, i);
             ap.st(0, alt_mv);
@@ -1882,7 +1883,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
         const bool ok = env0 < n_;
         const uint32_t env = (uint32_t)(ok ? env0 : n_ - 1);
         const void *rows = (const char *)p.obs + (size_t)v * F * n_ * ELEM;
-        int32_t *pairs = const_cast<int32_t *>(v == 0 ? p.opt.ego_pairs : p.opt.alt_pairs);
+        int32_t *pairs = (int32_t *)const_cast<void *>(v == 0 ? ego_src_ : alt_src_);
         if constexpr (SPLIT) {
           const int col = 32 * q + (lane & 31);
           ocpol::policy_pass<OT, 4, true, true>(rows, n32, env, ok, lane, p.pol[v].w1, p.pol[v].w2, p.pol[v].b2,
@@ -1911,11 +1912,14 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
 // launch (-mllvm -amdgpu-kernarg-preload-count, build.py), so the state and action loads are
 // issued without first waiting for a scalar kernarg load.  (block_ = workgroup size | which
 // optional action sources are in use << 16: the branches on them are taken on a preloaded SGPR,
-// not on a pointer that a scalar load has yet to deliver)
+// not on a pointer that a scalar load has yet to deliver; ego_src_ = opts.ego_pairs, alt_src_ =
+// opts.alt_rng or opts.alt_pairs: preloaded as well, so the general variant issues its action
+// loads with the state loads instead of behind a scalar round trip -- 3.57 -> 3.2 us per step)
 template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int SP, bool POL = false>
 __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
                                                     int32_t *const comm_, int64_t *const metrics_,
                                                     const int64_t n_, const int32_t block_,
+                                                    const void *const ego_src_, const void *const alt_src_,
                                                     const MultiArgs p) {
   static_assert(SP == 1 || SP == 2 || SP == 4, "waves per 64 envs");
   static_assert(SP != 2 || !POL, "the fused policies need the four-wave split");
@@ -1931,13 +1935,13 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   // (tests/test_host_cpu.py checks every kernel of every built library) and keep the parameter:
   // loads through the pointer are not known to be invariant, and cost them 3 % (tomato-2) to 28 %
   // (a random-* level, whose map geometry is read at run time).
-  struct KernArgs { int32_t *a; const int32_t *b; int32_t *c; int64_t *d; int64_t n; int32_t blk; MultiArgs p; };
+  struct KernArgs { int32_t *a; const int32_t *b; int32_t *c; int64_t *d; int64_t n; int32_t blk; const void *e, *f; MultiArgs p; };
   [[maybe_unused]] const MultiArgs &pk = *reinterpret_cast<const MultiArgs *>(
       reinterpret_cast<const char *>((const void *)__builtin_amdgcn_kernarg_segment_ptr()) + offsetof(KernArgs, p));
 #endif
-#define OC_BODY(duty) multi_step_body<M, LDS, OT, WT, DUP, XO, (duty), true, POL>(state_, actions_, comm_, metrics_, n_, block_, pk)
+#define OC_BODY(duty) multi_step_body<M, LDS, OT, WT, DUP, XO, (duty), true, POL>(state_, actions_, comm_, metrics_, n_, block_, ego_src_, alt_src_, pk)
   if constexpr (SP == 1) {
-    multi_step_body<M, LDS, OT, WT, DUP, XO, DUTY_ALL, false, POL>(state_, actions_, comm_, metrics_, n_, block_, p);
+    multi_step_body<M, LDS, OT, WT, DUP, XO, DUTY_ALL, false, POL>(state_, actions_, comm_, metrics_, n_, block_, ego_src_, alt_src_, p);
   } else {
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if constexpr (SP == 2) {   // two waves per 64 envs: state + viewer 0 | shaping + viewer 1
@@ -2005,7 +2009,8 @@ int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_
   const int32_t src = (a.opt.ego_pairs ? 1 : 0) | (a.opt.alt_pairs ? 2 : 0) | (a.opt.alt_rng ? 4 : 0) |
                       (a.opt.pairs_int64 ? 8 : 0);
   return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.comm, a.metrics, a.n,
-                  (int32_t)(block_size_for(n) | (src << 16)), a);
+                  (int32_t)(block_size_for(n) | (src << 16)), (const void *)a.opt.ego_pairs,
+                  a.opt.alt_rng ? (const void *)a.opt.alt_rng : (const void *)a.opt.alt_pairs, a);
 }
 
 // Split launch of the fused step (k_multi_step<..., SP = 4>): 256 threads per workgroup over
@@ -2017,7 +2022,8 @@ int launch_ms_split(K kernel, int sp, const MultiArgs &a, int64_t n, void *strea
   const int32_t src = (a.opt.ego_pairs ? 1 : 0) | (a.opt.alt_pairs ? 2 : 0) | (a.opt.alt_rng ? 4 : 0) |
                       (a.opt.pairs_int64 ? 8 : 0);
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * sp), 0, (hipStream_t)stream, a.state, a.actions,
-                     a.comm, a.metrics, a.n, (int32_t)(64 | (src << 16)), a);
+                     a.comm, a.metrics, a.n, (int32_t)(64 | (src << 16)), (const void *)a.opt.ego_pairs,
+                     a.opt.alt_rng ? (const void *)a.opt.alt_rng : (const void *)a.opt.alt_pairs, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "kernel launch");
   return OC_OK;

@@ -2,7 +2,7 @@
 """Diagnostic: where one wave of k_multi_step spends its cycles (s_memtime stamps).
 Builds a -DOC_STAMPS specialised library (never shipped, never timed), runs a few hundred
 steps and prints the median cycle count of every phase.  GPU box only.
-    python tools/stamp_phases.py [n] [waves per 64 envs: 0 = the library's choice, 1, 4]"""
+    python tools/stamp_phases.py [n] [waves per 64 envs: 0 = the library's choice, 1, 4] [pairs]"""
 import os
 import sys
 
@@ -30,9 +30,13 @@ def main():
     gen = torch.Generator(device="cuda").manual_seed(1)
     hi = torch.tensor([4, 2, 4, 2], device="cuda").view(4, 1)
     rows = []
+    pairs = len(sys.argv) > 3 and sys.argv[3] == "pairs"     # the general variant: actions as [n][2] pairs
     for k in range(300):
         a = (torch.rand((4, n), generator=gen, device="cuda") * hi).to(torch.int32)
-        env.multi_step(a)
+        if pairs:
+            env.multi_step(None, ego_pairs=a[0:2].T.contiguous(), alt_pairs=a[2:4].T.contiguous())
+        else:
+            env.multi_step(a)
         if k >= 100:
             rows.append(dbg.cpu().numpy().copy())
     t = np.stack(rows).astype(np.int64)          # [steps][waves][16]
