@@ -465,7 +465,9 @@ def main():
                        "kernel_flavour": env.kernel_flavour,
                        **({"launches_per_step": (1 if loop.one_launch else 2) if args.policy == "fused" else "torch"}
                           if closed else {}),
-                       "waves_per_64_envs": env.launch_waves_per_64 if wrapper else 1,
+                       # (the general variant the closed loop launches splits four ways or not at all)
+                       "waves_per_64_envs": ((env.launch_waves_per_64 if not closed or env.launch_waves_per_64 == 4 else 1)
+                                             if wrapper else 1),
                        "parallelism": "env-sharded x%d" % world},
             "agent_steps_per_sec": value * lv.num_agents,
             "timing": {"what": "median over back-to-back blocks of `steps` steps (`reps` of them, "
