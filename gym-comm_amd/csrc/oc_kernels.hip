@@ -1629,7 +1629,7 @@ __device__ __forceinline__ float *pol_lds_ts() {
 template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int DUTY, bool SPLIT, bool POL = false>
 __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int32_t *const actions_,
                                                 int32_t *const comm_, int64_t *const metrics_,
-                                                const int64_t n_, const int32_t block_, const void *const ego_src_,
+                                                const int32_t n_, const int32_t block_, const void *const ego_src_,
                                                 const void *const alt_src_, const MultiArgs &p) {
   constexpr int A = 2;
   constexpr bool D_STATE = (DUTY & DUTY_STATE) != 0, D_SHAPE = (DUTY & DUTY_SHAPE) != 0;
@@ -1735,7 +1735,9 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
                  "s"(L.deliv_pos(0)));
 #endif
     // episode statistics: the running return / length and the previous step's done flag are
-    // loaded now, with the state, and consumed after the last store of the step
+    // loaded now, with the state, and consumed after the last store of the step.  (Loading the
+    // totals behind the barrier instead -- they are the shaping wave's own -- was slower: vmcnt
+    // retires in order, so the shaping's distance lookups then waited for them: 3.64 -> 3.90 us.)
     double ep_ret = 0.0;
     int ep_len = 0, prev_done = 0;
     if (XO && p.opt.ep_return != nullptr) {   // uniform
@@ -1913,12 +1915,12 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
 // issued without first waiting for a scalar kernarg load.  (block_ = workgroup size | which
 // optional action sources are in use << 16: the branches on them are taken on a preloaded SGPR,
 // not on a pointer that a scalar load has yet to deliver; ego_src_ = opts.ego_pairs, alt_src_ =
-// opts.alt_rng or opts.alt_pairs: preloaded as well, so the general variant issues its action
-// loads with the state loads instead of behind a scalar round trip -- 3.57 -> 3.2 us per step)
+// opts.alt_rng or opts.alt_pairs: preloaded as well (n_ is 32 bits wide so that the lot fits the
+// 14 preloadable dwords), so the general variant issues its action loads with the state loads)
 template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int SP, bool POL = false>
 __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
                                                     int32_t *const comm_, int64_t *const metrics_,
-                                                    const int64_t n_, const int32_t block_,
+                                                    const int32_t n_, const int32_t block_,
                                                     const void *const ego_src_, const void *const alt_src_,
                                                     const MultiArgs p) {
   static_assert(SP == 1 || SP == 2 || SP == 4, "waves per 64 envs");
@@ -1935,7 +1937,7 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   // (tests/test_host_cpu.py checks every kernel of every built library) and keep the parameter:
   // loads through the pointer are not known to be invariant, and cost them 3 % (tomato-2) to 28 %
   // (a random-* level, whose map geometry is read at run time).
-  struct KernArgs { int32_t *a; const int32_t *b; int32_t *c; int64_t *d; int64_t n; int32_t blk; const void *e, *f; MultiArgs p; };
+  struct KernArgs { int32_t *a; const int32_t *b; int32_t *c; int64_t *d; int32_t n, blk; const void *e, *f; MultiArgs p; };
   [[maybe_unused]] const MultiArgs &pk = *reinterpret_cast<const MultiArgs *>(
       reinterpret_cast<const char *>((const void *)__builtin_amdgcn_kernarg_segment_ptr()) + offsetof(KernArgs, p));
 #endif
@@ -2008,7 +2010,7 @@ template <typename K>
 int launch_ms(K kernel, const MultiArgs &a, int64_t n, void *stream, size_t lds_bytes = 0) {
   const int32_t src = (a.opt.ego_pairs ? 1 : 0) | (a.opt.alt_pairs ? 2 : 0) | (a.opt.alt_rng ? 4 : 0) |
                       (a.opt.pairs_int64 ? 8 : 0);
-  return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.comm, a.metrics, a.n,
+  return launch_n(kernel, n, stream, lds_bytes, a.state, a.actions, a.comm, a.metrics, (int32_t)a.n,
                   (int32_t)(block_size_for(n) | (src << 16)), (const void *)a.opt.ego_pairs,
                   a.opt.alt_rng ? (const void *)a.opt.alt_rng : (const void *)a.opt.alt_pairs, a);
 }
@@ -2022,7 +2024,7 @@ int launch_ms_split(K kernel, int sp, const MultiArgs &a, int64_t n, void *strea
   const int32_t src = (a.opt.ego_pairs ? 1 : 0) | (a.opt.alt_pairs ? 2 : 0) | (a.opt.alt_rng ? 4 : 0) |
                       (a.opt.pairs_int64 ? 8 : 0);
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * sp), 0, (hipStream_t)stream, a.state, a.actions,
-                     a.comm, a.metrics, a.n, (int32_t)(64 | (src << 16)), (const void *)a.opt.ego_pairs,
+                     a.comm, a.metrics, (int32_t)a.n, (int32_t)(64 | (src << 16)), (const void *)a.opt.ego_pairs,
                      a.opt.alt_rng ? (const void *)a.opt.alt_rng : (const void *)a.opt.alt_pairs, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "kernel launch");

@@ -2,7 +2,7 @@
 """Diagnostic: where one wave of k_multi_step spends its cycles (s_memtime stamps).
 Builds a -DOC_STAMPS specialised library (never shipped, never timed), runs a few hundred
 steps and prints the median cycle count of every phase.  GPU box only.
-    python tools/stamp_phases.py [n] [waves per 64 envs: 0 = the library's choice, 1, 4] [pairs]"""
+    python tools/stamp_phases.py [n] [waves per 64 envs: 0 = the library's choice, 1, 4] [pairs | stats]"""
 import os
 import sys
 
@@ -22,7 +22,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     env = BatchedOvercooked("open-divider_tomato", num_agents=2, num_envs=n, max_num_timesteps=500,
                             num_communication=2, auto_reset=True, specialize_level=True,
-                            waves_per_64=int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+                            waves_per_64=int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                            episode_stats=len(sys.argv) > 3 and sys.argv[3] == "stats")   # rows + statistics: general variant
     sp = env.launch_waves_per_64    # waves per 64 envs (4 = split launch): the kernel writes one record per wave
     waves = (n + 63) // 64 * sp
     dbg = torch.zeros((waves, 16), dtype=torch.int64, device="cuda")
