@@ -209,6 +209,58 @@ def cpu_baseline(level_blob, A, C, wrapper, seconds):
                       % (n, steps, el, cores, steps1, el1)}
 
 
+def open_loop_workload(args, dev, seed, actions=None):
+    """The open-loop workload exactly as the timed region runs it: the batch (the library's own
+    launch choice unless --waves-per-64 says otherwise), a WINDOW-step window of pre-generated
+    actions resident in HBM, and ``step_fn(k)`` = one launch of the hot path on window step
+    ``k % WINDOW``.  `actions` (int32 [WINDOW][4 or A][n], on `dev`) replaces the seeded random
+    window: how tests/test_timed_path_gpu.py replays THIS path against the oracle."""
+    from gym_comm_amd.batched import BatchedOvercooked
+    n = args.envs
+    wrapper = args.agents == 2
+    env = BatchedOvercooked(args.level, num_agents=args.agents, num_envs=n,
+                            max_num_timesteps=args.T, num_communication=args.comm,
+                            communication_on=True, fow_radius=2, device=dev, auto_reset=True,
+                            obs_dtype=getattr(torch, args.obs_dtype), seed=seed,
+                            waves_per_64=args.waves_per_64)
+    rows = 4 if wrapper else args.agents
+    if actions is None:
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        if wrapper:
+            hi = torch.tensor([4, args.comm, 4, args.comm], device=dev).view(1, 4, 1)
+            actions = (torch.rand((WINDOW, 4, n), generator=gen, device=dev) * hi).to(torch.int32).contiguous()
+        else:
+            actions = torch.randint(0, 4, (WINDOW, args.agents, n), generator=gen, device=dev,
+                                    dtype=torch.int32)
+    elif tuple(actions.shape) != (WINDOW, rows, n) or actions.dtype != torch.int32:
+        raise ValueError("actions must be int32 [%d][%d][%d]" % (WINDOW, rows, n))
+    fn = env.multi_step if wrapper else env.step
+    acts = [actions[k].contiguous() for k in range(WINDOW)]
+    torch.cuda.synchronize(dev)          # reset + window are in HBM before any other stream steps
+    return env, (lambda k: fn(acts[k % WINDOW])), acts
+
+
+def reference_python_rate(level, agents, wrapper):
+    """The reference's OWN Python rate for this workload: a recorded figure (the reference cannot
+    travel to the GPU box), written by tests/golden/time_reference.py in the build container into
+    profiles/reference_cpu_rate.json -- read like profiles/traffic.json, labelled as stored."""
+    path = os.path.join(ROOT, "profiles", "reference_cpu_rate.json")
+    try:
+        with open(path) as f:
+            rj = json.load(f)
+        ent = rj["configs"]["%s_a%d_%s" % (level, agents, "wrapper" if wrapper else "base")]
+        best = max(ent["runs"], key=lambda r: r["procs"])
+        one = min(ent["runs"], key=lambda r: r["procs"])
+        return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["procs"],
+                "value_1core": one["env_steps_per_s"] / one["procs"],
+                "hardware": "%s (build container, %d cores)" % (rj["hardware"], rj["cores_available"]),
+                "call": ent["call"],
+                "source": "profiles/reference_cpu_rate.json (recorded %s by %s; not measured in this run)"
+                          % (rj.get("recorded"), rj.get("script"))}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 class StepBlocks:
     """K steps as hipGraph replays (K-step graphs of up to `G` steps + one tail graph), or as
     eager launches."""
@@ -277,7 +329,6 @@ def main():
             dist.init_process_group(args.backend)
 
     from gym_comm_amd import dist as ocdist
-    from gym_comm_amd.batched import BatchedOvercooked
     wrapper = args.agents == 2
     closed = args.mode == "closed-loop"
     if closed and not wrapper:
@@ -314,22 +365,7 @@ def main():
         step_fn = lambda k: loop.enqueue()             # captured K at a time by StepBlocks below
         obs_elem = 4
     else:
-        env = BatchedOvercooked(args.level, num_agents=args.agents, num_envs=n,
-                                max_num_timesteps=args.T, num_communication=args.comm,
-                                communication_on=True, fow_radius=2, device=dev, auto_reset=True,
-                                obs_dtype=getattr(torch, args.obs_dtype), seed=seed,
-                                waves_per_64=args.waves_per_64)
-        gen = torch.Generator(device=dev).manual_seed(seed)
-        if wrapper:
-            hi = torch.tensor([4, args.comm, 4, args.comm], device=dev).view(1, 4, 1)
-            acts = (torch.rand((WINDOW, 4, n), generator=gen, device=dev) * hi).to(torch.int32).contiguous()
-            fn = env.multi_step
-        else:
-            acts = torch.randint(0, 4, (WINDOW, args.agents, n), generator=gen, device=dev,
-                                 dtype=torch.int32)
-            fn = env.step
-        acts = [acts[k].contiguous() for k in range(WINDOW)]
-        step_fn = lambda k: fn(acts[k % WINDOW])
+        env, step_fn, _ = open_loop_workload(args, dev, seed)
         obs_elem = ELEM[args.obs_dtype]
     lv = env.level
 
@@ -418,13 +454,19 @@ def main():
     m = [g["total"][k] for k in ocdist.METRIC_NAMES]
 
     if rank == 0:
-        step_s = med_block_s / K
+        # N = 1: the median block (robust against a stray host hiccup between two replays, and what the
+        # HIP events on the launch stream saw).  N > 1: a per-rank median would hide a rank that stalls
+        # for part of the region, so the whole-node figure is the barrier-bracketed wall clock over the
+        # region (MAX over ranks); the median stays beside it.
+        med_step_s = med_block_s / K
+        wall_step_s = wall / (reps * K)
+        step_s = med_step_s if world == 1 else wall_step_s
         value = n * world / step_s
         A, M, S = lv.num_agents, lv.num_items, lv.num_subtasks
         rd, wr = layout_bytes_per_env_step(A, M, S, args.comm, wrapper, obs_elem)
         survey = survey_bytes_per_env_step(A, M, S, args.comm, wrapper, obs_elem)
-        achieved = (rd + wr) * n / step_s / 1e9
-        survey_gbps = survey * n / step_s / 1e9
+        achieved = (rd + wr) * n / med_step_s / 1e9        # the kernel's duration: HIP events, per rank
+        survey_gbps = survey * n / med_step_s / 1e9
         traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and not closed:
@@ -447,7 +489,8 @@ def main():
                       "env-steps/sec (whole node), closed loop: ego + partner policy in the loop",
             "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "reps": reps,
-            "ms_per_step": step_s * 1e3, "ms_per_step_wall": wall * 1e3 / (reps * K),
+            "ms_per_step": step_s * 1e3, "ms_per_step_wall": wall_step_s * 1e3,
+            "ms_per_step_median_block": med_step_s * 1e3,
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": args.obs_dtype if (not closed or args.policy == "fused") else "int32", "data": "synthetic",
@@ -473,6 +516,8 @@ def main():
             "timing": {"what": "median over back-to-back blocks of `steps` steps (`reps` of them, "
                                "`blocks_per_replay` per hipGraph replay), HIP events on the launch stream "
                                "between replays, MAX over ranks",
+                       "value_from": ("median block time (N = 1)" if world == 1 else
+                                      "barrier-bracketed wall clock over the region, MAX over ranks (N > 1)"),
                        "blocks_per_replay": bpr, "replays": replays, "settle_ms_untimed": SETTLE_MS,
                        "block_ms_min": block_s[0] * 1e3, "block_ms_median": med_block_s * 1e3,
                        "block_ms_max": block_s[-1] * 1e3, "region_wall_s": wall},
@@ -489,19 +534,21 @@ def main():
                          "observation rows, timestep, rewards, done, metrics atomics)",
                 "layout_bytes_per_env_step": {"read": rd, "written": wr},
                 "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_frac": (traffic / step_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "traffic_frac": (traffic / med_step_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                 # SURVEY 8(d)'s int32-per-field accounting, which this layout does not move: a
                 # labelled secondary rate; as a "fraction" only while it stays below 1
                 "survey_bytes_per_env_step": survey, "survey_bytes_gbps": survey_gbps,
                 "frac_survey_bytes": (survey_gbps / HBM_PEAK_GBPS) if survey_gbps <= HBM_PEAK_GBPS else None,
                 "kernel": kernel,
-                "avg_launch_us_timed_region": step_s * 1e6,
+                "avg_launch_us_timed_region": med_step_s * 1e6,
                 "avg_launch_us_event_bracketed": launch_ms_bracketed * 1e3}
         if not args.no_cpu_baseline and world == 1 and not closed:
             out["cpu_baseline"] = cpu_baseline(lv.blob, lv.num_agents, args.comm, wrapper,
                                                args.cpu_seconds)
+            out["cpu_baseline"]["reference_python"] = reference_python_rate(args.level, args.agents, wrapper)
         else:
-            out["cpu_baseline"] = None
+            out["cpu_baseline"] = {"skipped": "N>1" if world > 1 else
+                                   "closed-loop mode" if closed else "--no-cpu-baseline"}
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
