@@ -118,6 +118,10 @@ def parse(argv=None):
     p.add_argument("--waves-per-64", type=int, default=0, choices=[0, 1, 2, 4],
                    help="launch hint of the fused step: 0 = the library decides (four waves per 64 envs up to 24576 envs, two up to 32768), "
                         "1 = one wave per 64 envs, 2 / 4 = split launches (include/oc_hip.h, oc_step_opts)")
+    p.add_argument("--decompose", action="store_true",
+                   help="also replay the same graph on the TIMELINE build of the level's library (every wave "
+                        "stamps the chip-wide 100 MHz clock; include/oc_hip.h: oc_timeline_begin) and report "
+                        "roofline.kernel_active_us / boundary_us beside the unchanged headline")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -209,7 +213,7 @@ def cpu_baseline(level_blob, A, C, wrapper, seconds):
                       % (n, steps, el, cores, steps1, el1)}
 
 
-def open_loop_workload(args, dev, seed, actions=None):
+def open_loop_workload(args, dev, seed, actions=None, specialize_level="auto"):
     """The open-loop workload exactly as the timed region runs it: the batch (the library's own
     launch choice unless --waves-per-64 says otherwise), a WINDOW-step window of pre-generated
     actions resident in HBM, and ``step_fn(k)`` = one launch of the hot path on window step
@@ -222,7 +226,7 @@ def open_loop_workload(args, dev, seed, actions=None):
                             max_num_timesteps=args.T, num_communication=args.comm,
                             communication_on=True, fow_radius=2, device=dev, auto_reset=True,
                             obs_dtype=getattr(torch, args.obs_dtype), seed=seed,
-                            waves_per_64=args.waves_per_64)
+                            waves_per_64=args.waves_per_64, specialize_level=specialize_level)
     rows = 4 if wrapper else args.agents
     if actions is None:
         gen = torch.Generator(device=dev).manual_seed(seed)
@@ -259,6 +263,86 @@ def reference_python_rate(level, agents, wrapper):
                           % (rj.get("recorded"), rj.get("script"))}
     except (OSError, KeyError, ValueError):
         return None
+
+
+def decompose_step(args, dev, seed, stream, steps, min_ms=60.0):
+    """Split a step of the chained-launch graph into KERNEL-ACTIVE time and LAUNCH BOUNDARY without a
+    profiler: the same workload on the timeline build of the level's library (-DOC_TIMELINE: the
+    product source -- three reads of the chip-wide constant-rate clock and three plain stores per wave), one
+    `steps`-launch hipGraph whose launches each have their own record [4][waves] of {start,
+    issue-end, drain-end, shader cycles}; reduced over the waves to min start / max ends.  Per launch k:
+        active_k   = drain_end_k - start_k         waves of launch k on the chip
+        boundary_k = start_{k+1} - drain_end_k     last store acknowledged -> first wave of the next launch
+        period_k   = start_{k+1} - start_k         = active_k + boundary_k: the step, as the chip saw it
+    The clock ticks every 10 ns, so single values are quantised; means over >= 10^4 launches are not.
+    Returns a dict for roofline{} (times in us) -- measured on the timeline build, whose own
+    event-timed step is reported too so the perturbation is visible."""
+    import ctypes
+    env, step_fn, _ = open_loop_workload(args, dev, seed, specialize_level="timeline")
+    L = env._L
+    n = args.envs
+    stride = 4 * ((n + 63) // 64)                     # an upper bound of the waves of one launch
+    rec = torch.zeros((steps, 4, stride), dtype=torch.int64, device=dev)
+    init = torch.zeros((steps, 4, stride), dtype=torch.int64, device=dev)
+    init[:, 0] = torch.iinfo(torch.int64).max         # (the stamps are far below 2^63: signed min/max is fine)
+    with torch.cuda.stream(stream):
+        for k in range(8):
+            step_fn(k)
+        stream.synchronize()
+        rc = L.oc_timeline_begin(ctypes.c_void_p(rec.data_ptr()), steps, stride)
+        if rc:
+            raise SystemExit("oc_timeline_begin failed: %s" % L.oc_last_error().decode())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for k in range(steps):
+                step_fn(k)
+        L.oc_timeline_begin(None, 0, 0)
+        t_end = time.perf_counter() + SETTLE_MS / 1e3
+        while time.perf_counter() < t_end:
+            g.replay()
+            stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        act, iss, gap, per, ev_ms, nrep, life, spread, cyc = [], [], [], [], [], 0, [], [], []
+        waves = None
+        t_end = time.perf_counter() + 10.0
+        gpu_ms = 0.0
+        while gpu_ms < min_ms and time.perf_counter() < t_end:
+            rec.copy_(init)
+            stream.synchronize()
+            e0.record(stream)
+            g.replay()
+            e1.record(stream)
+            stream.synchronize()
+            # per launch: min start, max issue-end, max drain-end over the waves that wrote
+            start = rec[:, 0].min(dim=1).values
+            r = torch.stack([start, rec[:, 1].max(dim=1).values, rec[:, 2].max(dim=1).values], dim=1).cpu().numpy()
+            wrote = rec[:, 0] != torch.iinfo(torch.int64).max
+            waves = int(wrote[0].sum().item())
+            life.append(float(((rec[:, 2] - rec[:, 0]) * wrote).sum().item()) / max(1, int(wrote.sum().item())))
+            cyc.append(float(rec[:, 3].sum().item()) / max(1.0, float(((rec[:, 2] - rec[:, 0]) * wrote).sum().item())))
+            spread.append(float((torch.where(wrote, rec[:, 0], start.unsqueeze(1)).max(dim=1).values - start)
+                                .double().mean().item()))
+            ms = e0.elapsed_time(e1)
+            gpu_ms += ms
+            ev_ms.append(ms / steps)
+            act.append(r[:, 2] - r[:, 0])
+            iss.append(r[:, 1] - r[:, 0])
+            gap.append(r[1:, 0] - r[:-1, 2])
+            per.append(r[1:, 0] - r[:-1, 0])
+            nrep += 1
+    tick_us = 0.01                                     # s_memrealtime: 100 MHz (MI355X_MICROARCH.md)
+    cat = lambda xs: np.concatenate(xs).astype(np.float64) * tick_us
+    act, iss, gap, per = cat(act), cat(iss), cat(gap), cat(per)
+    stat = lambda x: {"mean": float(x.mean()), "median": float(np.median(x)), "p95": float(np.percentile(x, 95))}
+    return {"kernel_active_us": float(act.mean()), "boundary_us": float(gap.mean()),
+            "period_us": float(per.mean()), "issue_span_us": float(iss.mean()),
+            "kernel_active": stat(act), "boundary": stat(gap), "period": stat(per),
+            "wave_lifetime_us": float(np.mean(life)) * tick_us, "wave_start_spread_us": float(np.mean(spread)) * tick_us,
+            "shader_clock_mhz": float(np.mean(cyc)) * 100.0,      # s_memtime cycles per 10 ns realtime tick
+            "launches_sampled": int(act.size), "waves_per_launch": waves,
+            "timeline_build_event_us_per_step": float(np.median(ev_ms) * 1e3),
+            "method": "in-graph s_memrealtime stamps (100 MHz, chip-wide) on the -DOC_TIMELINE build of the "
+                      "level library: per launch min wave start / max drain end; no profiler attached"}
 
 
 class StepBlocks:
@@ -444,6 +528,9 @@ def main():
             stream.synchronize()
             per_launch_ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
             launch_ms_bracketed = float(np.mean(per_launch_ms[probe // 10: probe - probe // 10]))
+        decomp = None
+        if args.decompose and not closed and rank == 0:
+            decomp = decompose_step(args, dev, seed, stream, SB if use_graph else min(G, 240))
 
     # end-of-rollout metrics: the only collective on the path (RCCL all-gather, 64 B/rank)
     if dist is not None and args.backend != "nccl":
@@ -542,6 +629,14 @@ def main():
                 "kernel": kernel,
                 "avg_launch_us_timed_region": med_step_s * 1e6,
                 "avg_launch_us_event_bracketed": launch_ms_bracketed * 1e3}
+            if decomp is not None:
+                # the step as the chip saw it (timeline build): kernel-active + boundary = period, to be
+                # read against ms_per_step of the product build above
+                out["roofline"].update({
+                    "kernel_active_us": decomp["kernel_active_us"], "boundary_us": decomp["boundary_us"],
+                    "frac_kernel_active": (rd + wr) * n / (decomp["kernel_active_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                    "decompose": decomp,
+                    "decompose_closure": (decomp["kernel_active_us"] + decomp["boundary_us"]) / (med_step_s * 1e6)})
         if not args.no_cpu_baseline and world == 1 and not closed:
             out["cpu_baseline"] = cpu_baseline(lv.blob, lv.num_agents, args.comm, wrapper,
                                                args.cpu_seconds)

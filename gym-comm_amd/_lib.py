@@ -9,12 +9,13 @@ import os
 from . import build as _build
 
 _I32P = ctypes.POINTER(ctypes.c_int32)
-ABI_VERSION = 5          # include/oc_hip.h: OC_ABI_VERSION
+ABI_VERSION = 6          # include/oc_hip.h: OC_ABI_VERSION
 
 SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destroy",
            "oc_level_spec_source", "oc_is_specialized", "oc_level_subtask_info",
            "oc_metrics_slots", "oc_state_words", "oc_obs_rows", "oc_reset", "oc_step", "oc_obs",
-           "oc_obs_image", "oc_image_words", "oc_multi_step", "oc_multi_step_waves", "oc_random_actions"]
+           "oc_obs_image", "oc_image_words", "oc_multi_step", "oc_multi_step_waves", "oc_random_actions",
+           "oc_timeline_begin"]
 
 
 class ObsCfg(ctypes.Structure):
@@ -103,9 +104,10 @@ def _declare(L):
     L.oc_random_actions.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
     L.oc_multi_step_waves.argtypes = [ctypes.c_int64, ctypes.c_int32]
     L.oc_multi_step_waves.restype = ctypes.c_int32
+    L.oc_timeline_begin.argtypes = [vp, ctypes.c_int64, ctypes.c_int64]
     for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_level_subtask_info",
               "oc_reset", "oc_step",
-              "oc_obs", "oc_obs_image", "oc_multi_step", "oc_random_actions"):
+              "oc_obs", "oc_obs_image", "oc_multi_step", "oc_random_actions", "oc_timeline_begin"):
         getattr(L, f).restype = ctypes.c_int
     if L.oc_abi_version() != ABI_VERSION:
         raise OcError("liboc_hip.so ABI version mismatch")

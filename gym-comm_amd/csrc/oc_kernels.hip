@@ -121,6 +121,42 @@ struct RunCfg {
 #define OC_STAMP_PASS
 #endif
 
+#ifdef OC_TIMELINE
+// Diagnostic build flavour (never the product, never the headline): every wave of k_step /
+// k_multi_step reads the constant-rate 100 MHz counter (s_memrealtime: the same clock on every XCD,
+// unlike the per-XCD shader clock of s_memtime) when it starts, when its last instruction has been
+// issued and when its last store has been acknowledged, and lane 0 writes the three to the wave's
+// OWN words of the launch's record, uint64 [4][stride] (the fourth: the wave's lifetime in shader-clock
+// cycles, s_memtime -- against the realtime span it gives the shader clock the wave ran at) (plain stores: the first version folded them
+// with same-address atomics, 4 x 256 waves on one line, and the launch took 14.6 us instead of 3.1).
+// A graph of chained launches replayed on such a build yields, per launch, the span in which the
+// kernel had waves on the chip ("kernel-active") and the gap to the next launch's first wave (the
+// launch boundary) -- the split of ms_per_step that bench.py --decompose reports, without a
+// profiler attached (include/oc_hip.h: oc_timeline_begin).
+#define OC_TL_BEGIN()                                                            \
+  const unsigned long long oc_tl0_ = __builtin_amdgcn_s_memrealtime();           \
+  const unsigned long long oc_tc0_ = __builtin_amdgcn_s_memtime()
+#define OC_TL_END(ptr_, stride_)                                                                 \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    const unsigned long long oc_tl1_ = __builtin_amdgcn_s_memrealtime();                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+    const unsigned long long oc_tl2_ = __builtin_amdgcn_s_memrealtime();                         \
+    const unsigned long long oc_tc2_ = __builtin_amdgcn_s_memtime();                             \
+    unsigned long long *tl_ = (ptr_);                                                            \
+    if (tl_ != nullptr && (threadIdx.x & 63) == 0) {                                             \
+      const int64_t w_ = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);           \
+      tl_[w_] = oc_tl0_;                                                                         \
+      tl_[(stride_) + w_] = oc_tl1_;                                                             \
+      tl_[2 * (int64_t)(stride_) + w_] = oc_tl2_;                                                \
+      tl_[3 * (int64_t)(stride_) + w_] = oc_tc2_ - oc_tc0_;   /* shader-clock cycles, start to drain-end */ \
+    }                                                                                            \
+  } while (0)
+#else
+#define OC_TL_BEGIN() do { } while (0)
+#define OC_TL_END(ptr_, stride_) do { } while (0)
+#endif
+
 // The kernels read the level through ACCESSORS (L.W(), L.goal_tset(g), ...), one list of fields
 // (OC_HDR_FIELDS) for two header classes.  The fields come in two kinds:
 //   STRUCTURE  what the recipes and the item multiset fix -- subtask masks, goal objects, item
@@ -1279,6 +1315,8 @@ struct StepArgs {
   uint32_t *rng;
   int64_t n;
   int32_t auto_reset;
+  unsigned long long *timeline;   // OC_TIMELINE builds: this launch's record (else NULL, never read)
+  int64_t timeline_stride;
 };
 
 // (leading scalars: preloaded kernel arguments, see k_multi_step)
@@ -1367,6 +1405,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
   // auto-reset flag too: this kernel runs at the SGPR limit with 3-4 agents, and the compiler
   // otherwise loads each of them right before its first use and waits on the spot)
   static_assert(SP == 1 || (SP == 2 && !LDS), "waves per 64 envs");
+  OC_TL_BEGIN();
   if constexpr (SP == 1) {
     step_body<A, M, LDS, WT, DUP, PLAY, 3, false>(state_, actions_, metrics_, n_, launch_, T_, tables_, inv_max_path_, p);
   } else {
@@ -1376,6 +1415,7 @@ __global__ void __launch_bounds__(256) k_step(int32_t *const state_, const int32
     else
       step_body<A, M, LDS, WT, DUP, PLAY, 2, true>(state_, actions_, metrics_, n_, launch_, T_, tables_, inv_max_path_, p);
   }
+  OC_TL_END(p.timeline, p.timeline_stride);
 }
 
 struct ObsArgs {
@@ -1576,6 +1616,8 @@ struct MultiArgs {
   oc_wrap_cfg cfg;
   oc_step_policy pol[2]; // opt.policy by value (it is a host pointer), used by the POL variants
   int32_t pol_ksteps;
+  unsigned long long *timeline;   // OC_TIMELINE builds: this launch's record (else NULL, never read)
+  int64_t timeline_stride;
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
@@ -1926,6 +1968,7 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
   static_assert(SP == 1 || SP == 2 || SP == 4, "waves per 64 envs");
   static_assert(SP != 2 || !POL, "the fused policies need the four-wave split");
   static_assert(SP == 1 || !LDS, "the split launch reads the tables from global memory");
+  OC_TL_BEGIN();
 #ifdef OC_SPECIALIZED
   const MultiArgs &pk = p;
 #else
@@ -1957,11 +2000,33 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
     }
   }
 #undef OC_BODY
+  OC_TL_END(p.timeline, p.timeline_stride);
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// OC_TIMELINE builds: the launches that follow oc_timeline_begin() take consecutive records
+#ifdef OC_TIMELINE
+unsigned long long *g_timeline = nullptr;
+int64_t g_timeline_left = 0, g_timeline_stride = 0;
+#endif
+// `waves`: an upper bound of the waves the launch will have
+unsigned long long *timeline_next(int64_t waves, int64_t &stride) {
+  stride = 0;
+#ifdef OC_TIMELINE
+  if (g_timeline_left > 0 && waves <= g_timeline_stride) {
+    unsigned long long *r = g_timeline;
+    g_timeline += 4 * g_timeline_stride;
+    g_timeline_left--;
+    stride = g_timeline_stride;
+    return r;
+  }
+#endif
+  (void)waves;
+  return nullptr;
+}
+
 int block_size_for(int64_t) {
   // One wave per workgroup spreads a batch over the most CUs and measured fastest at every
   // batch size from 4 096 to 524 288 envs (MI355X sweeps, profiles/r01_v3_block_lds_sweep.txt,
@@ -2537,7 +2602,8 @@ int oc_step(const oc_level_t *lv, int32_t *state, const int32_t *actions, int32_
   if (auto_reset && lv->hdr.nscatter > 0 && !placement && !rng)
     return fail(OC_E_BADARG, "oc_step: auto_reset on a random-placement level needs `placement` or `rng`");
   StepArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, actions, reward, done, shaping,
-             metrics, placement, rng, n, auto_reset};
+             metrics, placement, rng, n, auto_reset, nullptr, 0};
+  a.timeline = timeline_next(4 * ((n + 63) / 64), a.timeline_stride);
   const int A_ = lv->hdr.A, M_ = lv->hdr.M;
   const bool D_ = lv->hdr.has_dup != 0;
   const bool pl = lv->run.play != 0;
@@ -2638,7 +2704,7 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   if (auto_reset && lv->hdr.nscatter > 0 && !placement && !rng)
     return fail(OC_E_BADARG, "oc_multi_step: auto_reset on a random-placement level needs `placement` or `rng`");
   MultiArgs a{lv->hdr, lv->run, lv->dev_tables, lv->n16, lv->quot_bytes, state, comm, actions, obs, timestep,
-              reward, done, sparse, metrics, placement, rng, o, n, auto_reset, *cfg, {}, 0};
+              reward, done, sparse, metrics, placement, rng, o, n, auto_reset, *cfg, {}, 0, nullptr, 0};
   if (o.policy) {   // the closed loop in one launch (oc_step_opts.policy)
 #ifndef OC_SPECIALIZED
     return fail(OC_E_BADARG, "oc_multi_step: opts.policy needs a specialised library (this is the generic one)");
@@ -2657,6 +2723,7 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
       return fail(OC_E_BADARG, "oc_multi_step: opts.policy handles at most 46 observation rows; use oc_policy_mlp");
     a.opt.policy = nullptr;   // (a host pointer: nothing on the device may look at it)
   }
+  a.timeline = timeline_next(4 * ((n + 63) / 64), a.timeline_stride);
   const size_t lds = (size_t)lv->n16 * 16;
   const bool in_lds = tables_in_lds(n);
   const int ot = cfg->obs.obs_int8;   // 0 int32, 1 int8, 2 float32
@@ -2739,6 +2806,22 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
 #endif
 #undef OC_MS_SPLIT
 #undef OC_MS_X
+}
+
+int oc_timeline_begin(uint64_t *records, int64_t count, int64_t stride) {
+#ifdef OC_TIMELINE
+  if ((records == nullptr) != (count == 0) || count < 0 || (count > 0 && stride < 1))
+    return fail(OC_E_BADARG, "oc_timeline_begin: bad argument");
+  g_timeline = (unsigned long long *)records;
+  g_timeline_left = count;
+  g_timeline_stride = stride;
+  return OC_OK;
+#else
+  (void)records;
+  (void)count;
+  (void)stride;
+  return fail(OC_E_BADARG, "oc_timeline_begin: not a timeline build of the library (-DOC_TIMELINE)");
+#endif
 }
 
 int32_t oc_multi_step_waves(int64_t n, int32_t hint) {

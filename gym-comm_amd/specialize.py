@@ -81,23 +81,31 @@ def _source_digest():
     return h
 
 
-def spec_key(blob, geometry=True) -> str:
+# build variants of a specialised library beside the product one (measurement only)
+VARIANT_FLAGS = {"": [], "timeline": ["-DOC_TIMELINE"]}    # include/oc_hip.h: oc_timeline_begin
+
+
+def spec_key(blob, geometry=True, variant="") -> str:
     h = _source_digest()
     h.update(b"level" if geometry else b"structure")
     h.update(spec_header_text(blob, geometry).encode())
+    if variant:
+        h.update(" ".join(VARIANT_FLAGS[variant]).encode())
     return h.hexdigest()[:16]
 
 
-def spec_lib_path(blob, geometry=True) -> str:
-    return os.path.join(SPEC_DIR, "liboc_spec_%s.so" % spec_key(blob, geometry))
+def spec_lib_path(blob, geometry=True, variant="") -> str:
+    return os.path.join(SPEC_DIR, "liboc_spec_%s.so" % spec_key(blob, geometry, variant))
 
 
-def ensure(blob, verbose=False, geometry=True, compile=True):
+def ensure(blob, verbose=False, geometry=True, compile=True, variant=""):
     """Return the path of the specialised library of this level (`geometry`: its level library,
     else its structure library), building it if needed.  Returns None when it is not cached and
-    cannot / may not be compiled (`compile=False`, no hipcc, a profiler attached)."""
+    cannot / may not be compiled (`compile=False`, no hipcc, a profiler attached).
+    `variant="timeline"`: the diagnostic flavour whose waves stamp the constant-rate clock
+    (bench.py --decompose); never picked by `load_for` unless asked for."""
     text = spec_header_text(blob, geometry)
-    key = spec_key(blob, geometry)
+    key = spec_key(blob, geometry, variant)
     path = os.path.join(SPEC_DIR, "liboc_spec_%s.so" % key)
     if os.path.exists(path):
         return path
@@ -125,6 +133,7 @@ def ensure(blob, verbose=False, geometry=True, compile=True):
     tmp_lib = "%s.%s.tmp" % (path, uniq)
     cmd = [hipcc, "--offload-arch=" + _build.ARCH] + _build.FLAGS
     cmd += ["-DOC_SPECIALIZED", '-DOC_SPEC_FILE="%s"' % hdr] + (["-DOC_SPEC_GEOMETRY"] if geometry else [])
+    cmd += VARIANT_FLAGS[variant]
     cmd += [os.path.join(_build.CSRC, s) for s in _build.SOURCES] + ["-o", tmp_lib]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -140,7 +149,8 @@ def ensure(blob, verbose=False, geometry=True, compile=True):
 def load_for(blob, mode="auto", verbose=False):
     """The library to use for a level: ('spec' | 'generic', typed CDLL).
     mode: True (must specialise), False (generic), 'auto' (specialise when possible),
-    'structure' (the structure library: tests, measurements).  Order for True / 'auto': cached
+    'structure' (the structure library: tests, measurements), 'timeline' (the level library's
+    -DOC_TIMELINE flavour: measurements).  Order for True / 'auto': cached
     level library, cached structure library, a level library compiled now, generic."""
     if os.environ.get("OC_SPECIALIZE") == "0" and mode == "auto":
         mode = False
@@ -148,6 +158,11 @@ def load_for(blob, mode="auto", verbose=False):
         mode = "structure"          # (measurements / a test-suite pass on the structure libraries)
     if mode is False:
         return "generic", _lib.load()
+    if mode == "timeline":          # measurement flavour of the level library (bench.py --decompose)
+        path = ensure(blob, verbose=verbose, geometry=True, variant="timeline")
+        if path is None:
+            raise _lib.OcError("no cached timeline library for this level and hipcc is unavailable")
+        return "spec", _lib.load(path)
     if mode == "structure":
         path = ensure(blob, verbose=verbose, geometry=False)
         if path is None:

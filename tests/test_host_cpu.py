@@ -97,7 +97,8 @@ def test_c_abi_exports_every_declared_symbol():
     L = _lib.load()
     for sym in declared:
         assert getattr(L, sym) is not None
-    assert L.oc_abi_version() == _lib.ABI_VERSION == 5
+    assert L.oc_abi_version() == _lib.ABI_VERSION == 6
+    assert L.oc_timeline_begin(None, 0, 0) == -1 and b"timeline" in L.oc_last_error()    # the product build refuses
     # argument validation happens before any device work
     assert L.oc_step(None, None, None, None, None, None, 0, None, None, None, 0, None) == -1
     assert b"oc_step" in L.oc_last_error()

@@ -194,3 +194,43 @@ def test_bench_self_spawned_two_ranks_gloo_same_gpu():
     assert j["cpu_baseline"] == {"skipped": "N>1"}
     assert abs(j["value"] - 2 * 4096 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
     assert j["timing"]["value_from"].startswith("barrier-bracketed wall")
+
+
+def test_timeline_build_records_every_launch_and_steps_identically():
+    """The -DOC_TIMELINE flavour behind ``bench.py --decompose`` (include/oc_hip.h: oc_timeline_begin):
+    same results as the product build, one record per launch with every wave counted and
+    start <= issue-end <= drain-end per wave, no overlap between launches."""
+    import ctypes
+    from gym_comm_amd.batched import BatchedOvercooked
+    n, steps = 4096, 64
+    mk = lambda mode: BatchedOvercooked("open-divider_tomato", num_envs=n, max_num_timesteps=40, device="cuda:0",
+                                        specialize_level=mode)
+    prod, tl = mk("auto"), mk("timeline")
+    assert prod._L.oc_timeline_begin(None, 0, 0) != 0       # the product build refuses
+    acts = torch.randint(0, 2, (steps, 4, n), dtype=torch.int32, device="cuda")
+    acts[:, 0] = torch.randint(0, 4, (steps, n), dtype=torch.int32, device="cuda")
+    acts[:, 2] = torch.randint(0, 4, (steps, n), dtype=torch.int32, device="cuda")
+    stride = 4 * (n // 64)
+    rec = torch.zeros((steps, 4, stride), dtype=torch.int64, device="cuda")
+    rec[:, 0] = -1
+    assert tl._L.oc_timeline_begin(ctypes.c_void_p(rec.data_ptr()), steps, stride) == 0
+    for k in range(steps):
+        prod.multi_step(acts[k])
+        tl.multi_step(acts[k])
+    tl.multi_step(acts[0])                                   # past the last record: not recorded
+    prod.multi_step(acts[0])
+    assert tl._L.oc_timeline_begin(None, 0, 0) == 0
+    torch.cuda.synchronize()
+    for name in ("state", "obs", "comm", "done", "reward"):
+        assert torch.equal(getattr(prod, name), getattr(tl, name)), name
+    assert torch.equal(prod.shaped_reward.view(torch.int64), tl.shaped_reward.view(torch.int64))
+    r = rec.cpu().numpy()
+    waves = (n // 64) * tl.launch_waves_per_64
+    assert (r[:, 0, :waves] > 0).all() and (r[:, 0, waves:] == -1).all() and (r[:, 1:, waves:] == 0).all()
+    r = r[:, :, :waves]
+    mhz = 100.0 * r[:, 3].sum() / (r[:, 2] - r[:, 0]).sum()
+    assert 500 < mhz < 3000, mhz                            # the shader clock the waves ran at
+    assert (r[:, 0] <= r[:, 1]).all() and (r[:, 1] <= r[:, 2]).all()
+    start, end = r[:, 0].min(axis=1), r[:, 2].max(axis=1)
+    assert (start[1:] >= end[:-1]).all()                     # launches of one stream do not overlap
+    assert ((end - start) < 100000).all()                    # < 1 ms at 100 MHz
