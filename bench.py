@@ -265,26 +265,20 @@ def reference_python_rate(level, agents, wrapper):
         return None
 
 
-def decompose_step(args, dev, seed, stream, steps, min_ms=60.0):
-    """Split a step of the chained-launch graph into KERNEL-ACTIVE time and LAUNCH BOUNDARY without a
-    profiler: the same workload on the timeline build of the level's library (-DOC_TIMELINE: the
-    product source -- three reads of the chip-wide constant-rate clock and three plain stores per wave), one
-    `steps`-launch hipGraph whose launches each have their own record [4][waves] of {start,
-    issue-end, drain-end, shader cycles}; reduced over the waves to min start / max ends.  Per launch k:
-        active_k   = drain_end_k - start_k         waves of launch k on the chip
-        boundary_k = start_{k+1} - drain_end_k     last store acknowledged -> first wave of the next launch
-        period_k   = start_{k+1} - start_k         = active_k + boundary_k: the step, as the chip saw it
-    The clock ticks every 10 ns, so single values are quantised; means over >= 10^4 launches are not.
-    Returns a dict for roofline{} (times in us) -- measured on the timeline build, whose own
-    event-timed step is reported too so the perturbation is visible."""
+def _timeline_run(args, dev, seed, stream, steps, variant, min_ms):
+    """One timeline flavour of the level's library: capture `steps` launches with a record each,
+    replay for >= min_ms of GPU time; returns per-launch arrays (10 ns ticks) and per-wave means."""
     import ctypes
-    env, step_fn, _ = open_loop_workload(args, dev, seed, specialize_level="timeline")
+    env, step_fn, _ = open_loop_workload(args, dev, seed, specialize_level=variant)
     L = env._L
     n = args.envs
+    BIG = torch.iinfo(torch.int64).max                # (the stamps are far below 2^63: signed min/max is fine)
     stride = 4 * ((n + 63) // 64)                     # an upper bound of the waves of one launch
     rec = torch.zeros((steps, 4, stride), dtype=torch.int64, device=dev)
     init = torch.zeros((steps, 4, stride), dtype=torch.int64, device=dev)
-    init[:, 0] = torch.iinfo(torch.int64).max         # (the stamps are far below 2^63: signed min/max is fine)
+    init[:, 0] = BIG
+    end_row = 2 if variant == "timeline-drain" else 1
+    out = {k: [] for k in ("start", "end", "issue", "life", "spread", "mhz", "ev_us")}
     with torch.cuda.stream(stream):
         for k in range(8):
             step_fn(k)
@@ -302,8 +296,6 @@ def decompose_step(args, dev, seed, stream, steps, min_ms=60.0):
             g.replay()
             stream.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        act, iss, gap, per, ev_ms, nrep, life, spread, cyc = [], [], [], [], [], 0, [], [], []
-        waves = None
         t_end = time.perf_counter() + 10.0
         gpu_ms = 0.0
         while gpu_ms < min_ms and time.perf_counter() < t_end:
@@ -313,36 +305,77 @@ def decompose_step(args, dev, seed, stream, steps, min_ms=60.0):
             g.replay()
             e1.record(stream)
             stream.synchronize()
-            # per launch: min start, max issue-end, max drain-end over the waves that wrote
-            start = rec[:, 0].min(dim=1).values
-            r = torch.stack([start, rec[:, 1].max(dim=1).values, rec[:, 2].max(dim=1).values], dim=1).cpu().numpy()
-            wrote = rec[:, 0] != torch.iinfo(torch.int64).max
-            waves = int(wrote[0].sum().item())
-            life.append(float(((rec[:, 2] - rec[:, 0]) * wrote).sum().item()) / max(1, int(wrote.sum().item())))
-            cyc.append(float(rec[:, 3].sum().item()) / max(1.0, float(((rec[:, 2] - rec[:, 0]) * wrote).sum().item())))
-            spread.append(float((torch.where(wrote, rec[:, 0], start.unsqueeze(1)).max(dim=1).values - start)
-                                .double().mean().item()))
+            wrote = rec[:, 0] != BIG
+            start = rec[:, 0].min(dim=1).values        # per launch, over the waves that wrote
+            out["start"].append(start.cpu().numpy())
+            out["end"].append(rec[:, end_row].max(dim=1).values.cpu().numpy())
+            out["issue"].append(rec[:, 1].max(dim=1).values.cpu().numpy())
+            span = ((rec[:, end_row] - rec[:, 0]) * wrote).sum().double()
+            out["life"].append(float(span.item()) / max(1, int(wrote.sum().item())))
+            out["mhz"].append(100.0 * float(rec[:, 3].sum().item()) / max(1.0, float(span.item())))
+            out["spread"].append(float((torch.where(wrote, rec[:, 0], start.unsqueeze(1)).max(dim=1).values - start)
+                                       .double().mean().item()))
             ms = e0.elapsed_time(e1)
             gpu_ms += ms
-            ev_ms.append(ms / steps)
-            act.append(r[:, 2] - r[:, 0])
-            iss.append(r[:, 1] - r[:, 0])
-            gap.append(r[1:, 0] - r[:-1, 2])
-            per.append(r[1:, 0] - r[:-1, 0])
-            nrep += 1
+            out["ev_us"].append(ms / steps * 1e3)
+        out["waves"] = int(wrote[0].sum().item())
+        # by position of the wave in its workgroup (the last replay): mean start / end offset from the
+        # launch's first wave start -- which waves start late, which end last
+        wpw = max(1, out["waves"] // max(1, (n + 63) // 64))
+        out["by_wave_in_workgroup"] = []
+        for j in range(wpw):
+            sel = rec[:, :, j:out["waves"]:wpw]
+            out["by_wave_in_workgroup"].append({
+                "start_us": float((sel[:, 0] - start.unsqueeze(1)).double().mean().item()) * 0.01,
+                "end_us": float((sel[:, end_row] - start.unsqueeze(1)).double().mean().item()) * 0.01})
+    return out
+
+
+def decompose_step(args, dev, seed, stream, steps, min_ms=60.0):
+    """Split a step of the chained-launch graph into KERNEL-ACTIVE time and LAUNCH BOUNDARY without a
+    profiler: the same workload on the TIMELINE build of the level's library (-DOC_TIMELINE=1: the
+    product source + two reads of the chip-wide constant-rate clock and four write-through stores
+    by one lane per wave), one `steps`-launch hipGraph whose launches each have their own record
+    [4][waves]; reduced over the waves.  Per launch k:
+        active_k   = max issue-end_k - min start_k        waves of launch k on the chip
+        boundary_k = min start_{k+1} - max issue-end_k     store drain, end-of-kernel cache work, the
+                                                           command processor, the next dispatch
+        period_k   = active_k + boundary_k                 the step, as the chip saw it
+    A second pass on the -DOC_TIMELINE=2 flavour (every wave also WAITS for its stores and stamps
+    that) says how much of the boundary is store drain (`store_drain_us`; that flavour is slower:
+    its waves outlive their stores).  The clock ticks every 10 ns, so single values are quantised;
+    means over >= 10^4 launches are not.  Times in us; the timeline build's own event-timed step is
+    reported too, so its perturbation is visible (`decompose_closure` in the bench line = period /
+    the product build's ms_per_step)."""
     tick_us = 0.01                                     # s_memrealtime: 100 MHz (MI355X_MICROARCH.md)
+    r = _timeline_run(args, dev, seed, stream, steps, "timeline", min_ms)
     cat = lambda xs: np.concatenate(xs).astype(np.float64) * tick_us
-    act, iss, gap, per = cat(act), cat(iss), cat(gap), cat(per)
+    s_, e_ = np.stack(r["start"]), np.stack(r["end"])
+    act = ((e_ - s_).astype(np.float64) * tick_us).ravel()
+    gap = ((s_[:, 1:] - e_[:, :-1]).astype(np.float64) * tick_us).ravel()
+    per = ((s_[:, 1:] - s_[:, :-1]).astype(np.float64) * tick_us).ravel()
     stat = lambda x: {"mean": float(x.mean()), "median": float(np.median(x)), "p95": float(np.percentile(x, 95))}
-    return {"kernel_active_us": float(act.mean()), "boundary_us": float(gap.mean()),
-            "period_us": float(per.mean()), "issue_span_us": float(iss.mean()),
-            "kernel_active": stat(act), "boundary": stat(gap), "period": stat(per),
-            "wave_lifetime_us": float(np.mean(life)) * tick_us, "wave_start_spread_us": float(np.mean(spread)) * tick_us,
-            "shader_clock_mhz": float(np.mean(cyc)) * 100.0,      # s_memtime cycles per 10 ns realtime tick
-            "launches_sampled": int(act.size), "waves_per_launch": waves,
-            "timeline_build_event_us_per_step": float(np.median(ev_ms) * 1e3),
-            "method": "in-graph s_memrealtime stamps (100 MHz, chip-wide) on the -DOC_TIMELINE build of the "
-                      "level library: per launch min wave start / max drain end; no profiler attached"}
+    out = {"kernel_active_us": float(act.mean()), "boundary_us": float(gap.mean()), "period_us": float(per.mean()),
+           "kernel_active": stat(act), "boundary": stat(gap), "period": stat(per),
+           "wave_lifetime_us": float(np.mean(r["life"])) * tick_us,
+           "wave_start_spread_us": float(np.mean(r["spread"])) * tick_us,
+           "shader_clock_mhz": float(np.mean(r["mhz"])),   # s_memtime cycles per 10 ns realtime tick x 100
+           "launches_sampled": int(act.size), "waves_per_launch": r["waves"],
+           "by_wave_in_workgroup": r["by_wave_in_workgroup"],
+           "timeline_build_event_us_per_step": float(np.median(r["ev_us"])),
+           "method": "in-graph s_memrealtime stamps (100 MHz, chip-wide) on the -DOC_TIMELINE build of the "
+                     "level library: per launch min wave start / max wave end; no profiler attached"}
+    try:
+        d = _timeline_run(args, dev, seed, stream, steps, "timeline-drain", min_ms / 2)
+        ds, de, di = np.stack(d["start"]), np.stack(d["end"]), np.stack(d["issue"])
+        out["store_drain_us"] = float(((de - di).astype(np.float64) * tick_us).mean())
+        out["drain_build"] = {"kernel_active_to_drain_us": float(((de - ds) * tick_us).mean()),
+                              "boundary_after_drain_us": float(((ds[:, 1:] - de[:, :-1]) * tick_us).mean()),
+                              "event_us_per_step": float(np.median(d["ev_us"]))}
+    except Exception as exc:                           # the drain flavour is optional evidence
+        out["store_drain_us"] = None
+        out["drain_build"] = {"unavailable": str(exc)[:200]}
+    return out
 
 
 class StepBlocks:

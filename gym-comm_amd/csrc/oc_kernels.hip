@@ -124,15 +124,19 @@ struct RunCfg {
 #ifdef OC_TIMELINE
 // Diagnostic build flavour (never the product, never the headline): every wave of k_step /
 // k_multi_step reads the constant-rate 100 MHz counter (s_memrealtime: the same clock on every XCD,
-// unlike the per-XCD shader clock of s_memtime) when it starts, when its last instruction has been
-// issued and when its last store has been acknowledged, and lane 0 writes the three to the wave's
-// OWN words of the launch's record, uint64 [4][stride] (the fourth: the wave's lifetime in shader-clock
-// cycles, s_memtime -- against the realtime span it gives the shader clock the wave ran at) (plain stores: the first version folded them
-// with same-address atomics, 4 x 256 waves on one line, and the launch took 14.6 us instead of 3.1).
-// A graph of chained launches replayed on such a build yields, per launch, the span in which the
-// kernel had waves on the chip ("kernel-active") and the gap to the next launch's first wave (the
-// launch boundary) -- the split of ms_per_step that bench.py --decompose reports, without a
-// profiler attached (include/oc_hip.h: oc_timeline_begin).
+// unlike the per-XCD shader clock of s_memtime) when it starts and when its last instruction has
+// been issued, and lane 0 writes them -- and the wave's lifetime in shader-clock cycles -- to the
+// wave's OWN words of the launch's record, uint64 [4][stride].  A graph of chained launches
+// replayed on such a build yields, per launch, the span in which the kernel had waves on the chip
+// ("kernel-active") and the gap to the next launch's first wave (the launch boundary: store drain,
+// end-of-kernel cache work, the command processor, the next dispatch) -- the split of ms_per_step
+// that bench.py --decompose reports, without a profiler attached (include/oc_hip.h:
+// oc_timeline_begin).  -DOC_TIMELINE=2 additionally waits for the wave's stores (s_waitcnt
+// vmcnt(0)) and stamps that too: how much of the boundary is store drain.
+// Two earlier forms perturbed what they measured: same-address atomics (4 x 256 waves on one
+// line: 14.6 us per launch instead of 3.1), and a store wait + default-policy stamp stores in every
+// wave (+0.45 us: the wave outlives its stores and leaves dirty lines for the end-of-kernel
+// write-back); the stamp stores are write-through (sc1) like the step's own.
 #define OC_TL_BEGIN()                                                            \
   const unsigned long long oc_tl0_ = __builtin_amdgcn_s_memrealtime();           \
   const unsigned long long oc_tc0_ = __builtin_amdgcn_s_memtime()
@@ -140,16 +144,23 @@ struct RunCfg {
   do {                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     const unsigned long long oc_tl1_ = __builtin_amdgcn_s_memrealtime();                         \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
-    const unsigned long long oc_tl2_ = __builtin_amdgcn_s_memrealtime();                         \
+    unsigned long long oc_tl2_ = 0;                                                              \
+    if (OC_TIMELINE >= 2) {                                                                      \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+      oc_tl2_ = __builtin_amdgcn_s_memrealtime();                                                \
+    }                                                                                            \
     const unsigned long long oc_tc2_ = __builtin_amdgcn_s_memtime();                             \
     unsigned long long *tl_ = (ptr_);                                                            \
     if (tl_ != nullptr && (threadIdx.x & 63) == 0) {                                             \
+      typedef int v2i_ __attribute__((ext_vector_type(2)));                                      \
       const int64_t w_ = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);           \
-      tl_[w_] = oc_tl0_;                                                                         \
-      tl_[(stride_) + w_] = oc_tl1_;                                                             \
-      tl_[2 * (int64_t)(stride_) + w_] = oc_tl2_;                                                \
-      tl_[3 * (int64_t)(stride_) + w_] = oc_tc2_ - oc_tc0_;   /* shader-clock cycles, start to drain-end */ \
+      const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc(tl_, 0, 0x7FFFFFFF, 0x00020000); \
+      const int sb_ = (int)(stride_) * 8;                                                        \
+      const unsigned long long cyc_ = oc_tc2_ - oc_tc0_;                                         \
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_, oc_tl0_), r_, (int)w_ * 8, 0, 16);       \
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_, oc_tl1_), r_, (int)w_ * 8, sb_, 16);     \
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_, oc_tl2_), r_, (int)w_ * 8, 2 * sb_, 16); \
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_, cyc_), r_, (int)w_ * 8, 3 * sb_, 16);    \
     }                                                                                            \
   } while (0)
 #else
@@ -332,6 +343,38 @@ __device__ __forceinline__ void pack(const Env<A, M, DUP> &e, int32_t *w) {
   w[A + M + 1] = e.goalcnt;
   if constexpr (DUP) w[A + M + 2] = e.kn[0], w[A + M + 3] = e.kn[1];
 }
+
+// ---------------------------------------------------------------------------
+// per-lane predicates as VALU words
+// ---------------------------------------------------------------------------
+// A per-lane `bool` of the compiler lives in an SGPR pair (v_cmp -> s[n:n+1]) and its logic runs on
+// the scalar unit (s_and_b64 / s_or_b64 ...), to come back through v_cndmask.  On gfx950 a scalar
+// instruction that reads an SGPR a VECTOR instruction has just written stalls a lone wave ~16
+// cycles (tools/issue_probe.hip, one wave on a SIMD: v_cmp + s_and = 24 cycles, the chain v_cmp ->
+// s_and -> v_cndmask 28; the same decision on 0 / -1 words in VGPRs -- v_cmp/v_cndmask or
+// v_bfe_i32 to make the word, v_and / v_or / v_bitop3 for the logic, v_bfi to select -- 4 per
+// instruction), and interact()'s decision tree is a few hundred such hops: the step kernels ran
+// at ~7 cycles per instruction where 4 is the issue rate.  So every per-lane predicate of the hot
+// path is a P: an int that is 0 or -1, made opaque to the optimiser where it is born (`hide`:
+// an empty asm; otherwise InstCombine folds and/or of sign-extended compares back into i1 logic
+// and the backend selects the scalar unit again).
+typedef int P;
+__device__ __forceinline__ int hide(int v) {
+  asm("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ P p_eq(int a, int b) { return hide(a == b ? -1 : 0); }
+__device__ __forceinline__ P p_ne(int a, int b) { return hide(a != b ? -1 : 0); }
+__device__ __forceinline__ P p_gt_u(unsigned a, unsigned b) { return hide(a > b ? -1 : 0); }
+__device__ __forceinline__ P p_ge_u(unsigned a, unsigned b) { return hide(a >= b ? -1 : 0); }
+__device__ __forceinline__ P p_lt_u(unsigned a, unsigned b) { return hide(a < b ? -1 : 0); }
+__device__ __forceinline__ P p_gt_i(int a, int b) { return hide(a > b ? -1 : 0); }
+__device__ __forceinline__ P p_le_i(int a, int b) { return hide(a <= b ? -1 : 0); }
+__device__ __forceinline__ P p_nz(int a) { return hide(a != 0 ? -1 : 0); }
+__device__ __forceinline__ P p_z(int a) { return hide(a == 0 ? -1 : 0); }
+__device__ __forceinline__ P p_bit(int w, unsigned k) { return __builtin_amdgcn_sbfe(w, k, 1u); }  // bit k as 0 / -1: one v_bfe_i32
+__device__ __forceinline__ P p_of(bool uniform) { return uniform ? -1 : 0; }                       // a wave-uniform condition
+__device__ __forceinline__ int sel(P m, int a, int b) { return (a & m) | (b & ~m); }               // v_bfi_b32
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 // |a - b| + c on unsigned operands in one instruction (hipcc expands __sad() into compare,
@@ -766,108 +809,123 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
                                          ShapeLoads<(A < 2 ? A : 2)> &sld OC_STAMP_PARAM) {
   const int W = L.W(), H = L.H();
   e.t = min(e.t + 1, 0xFFFF);  // :213 (16-bit field: saturates; max_num_timesteps <= 65535 is enforced)
+  static_assert(OC_ACT_NOOP == 4 && OC_FLOOR == 0 && OC_COUNTER == 1 && OC_CUTBOARD == 2 && OC_DELIVERY == 3, "codes");
 
   // ---- check_collisions (:578-613) on the ORIGINAL actions -------------------
-  int act[A], np[A], tgt_p[A], tgt_ct[A];   // action, proposed cell, interact()'s target cell and its tile type
+  // (per-lane predicates are P words, 0 / -1: see `hide`)
+  int act[A], np[A], tgt_p[A];   // action, proposed cell, interact()'s target cell
+  P moving[A], t_nonfloor[A], t_deliv[A], t_cutb[A];   // action != (0,0); tile type of the target cell
 #pragma unroll
   for (int a = 0; a < A; a++) {
     int c = act_in[a];
-    if ((unsigned)c > 4u) e.err |= OC_ERR_ACTION;   // no such NAV action: flagged, executed as (0, 0)
-    c = (unsigned)c > 4u ? OC_ACT_NOOP : c;
+    e.err |= p_gt_u((unsigned)c, 4u) & OC_ERR_ACTION;   // no such NAV action: flagged, executed as (0, 0)
+    c = (int)min((unsigned)c, 4u);
     act[a] = c;
+    moving[a] = p_ne(c, OC_ACT_NOOP);
+    int cell;   // dense index of the target cell
+    P oob = 0;
     if constexpr (OC_BORDER_CLOSED) {
       // packed cell += {+16, -16, -1, +1, 0}: one signed byte per action code
       constexpr uint64_t STEP = 0x0001FFF010ull;  // NOOP 00 | RIGHT 01 | LEFT ff | UP f0 | DOWN 10
       const int q = e.ap[a] + (int)(int8_t)(STEP >> (8 * c));
       tgt_p[a] = q;
-      tgt_ct[a] = cell_type(L, dense(L, q));
-      np[a] = tgt_ct[a] != OC_FLOOR ? e.ap[a] : q;  // :551-559
+      cell = dense(L, q);
     } else {
       const int dx = (c == OC_ACT_RIGHT) - (c == OC_ACT_LEFT);
       const int dy = (c == OC_ACT_DOWN) - (c == OC_ACT_UP);
       const int qx = px(e.ap[a]) + dx, qy = py(e.ap[a]) + dy;
-      const bool inb = (unsigned)qx < (unsigned)W && (unsigned)qy < (unsigned)H;
-      if (!inb) e.err |= OC_ERR_OOB;  // get_gridsquare_at asserts (utils/world.py:310-315)
+      oob = ~(p_lt_u((unsigned)qx, (unsigned)W) & p_lt_u((unsigned)qy, (unsigned)H));
+      e.err |= oob & OC_ERR_OOB;  // get_gridsquare_at asserts (utils/world.py:310-315)
       const int tx = min(max(qx, 0), W - 1), ty = min(max(qy, 0), H - 1);  // world.inbounds (world.py:317-320)
       tgt_p[a] = tx | (ty << 4);
-      tgt_ct[a] = cell_type(L, ty * W + tx);
-      const bool blocked = !inb || (tgt_ct[a] != OC_FLOOR);
-      np[a] = blocked ? e.ap[a] : tgt_p[a];  // :551-559
+      cell = ty * W + tx;
     }
+    // tile type of the target cell as three predicates, straight from the bit-planes
+    P lo, hi;
+    if (!L.planes128()) {   // uniform (compile-time in specialised builds)
+      lo = p_bit((int)(L.cell_lo(0) >> cell), 0);
+      hi = p_bit((int)(L.cell_hi(0) >> cell), 0);
+    } else {
+      lo = -bit128(L.cell_lo(0), L.cell_lo(1), cell);
+      hi = -bit128(L.cell_hi(0), L.cell_hi(1), cell);
+    }
+    t_nonfloor[a] = lo | hi;
+    t_deliv[a] = lo & hi;
+    t_cutb[a] = hi & ~lo;
+    np[a] = sel(t_nonfloor[a] | oob, e.ap[a], tgt_p[a]);  // :551-559
   }
-  bool ex[A];
+  P ex[A];
 #pragma unroll
-  for (int a = 0; a < A; a++) ex[a] = true;
+  for (int a = 0; a < A; a++) ex[a] = -1;
 #pragma unroll
   for (int i = 0; i < A; i++)
 #pragma unroll
     for (int j = i + 1; j < A; j++) {
-      const bool same = np[i] == np[j];  // :562-569
-      const bool i_stays = np[i] == e.ap[i] && act[i] != OC_ACT_NOOP;
-      const bool j_stays = np[j] == e.ap[j] && act[j] != OC_ACT_NOOP;
-      const bool swap = e.ap[i] == np[j] && e.ap[j] == np[i];  // :572-575
-      const bool block_i = same ? !i_stays : swap;
-      const bool block_j = same ? (i_stays || !j_stays) : swap;
-      ex[i] = ex[i] && !block_i;
-      ex[j] = ex[j] && !block_j;
+      const P same = p_eq(np[i], np[j]);  // :562-569
+      const P i_stays = p_eq(np[i], e.ap[i]) & moving[i];
+      const P j_stays = p_eq(np[j], e.ap[j]) & moving[j];
+      const P swap = p_eq(e.ap[i], np[j]) & p_eq(e.ap[j], np[i]);  // :572-575
+      const P block_i = sel(same, ~i_stays, swap);
+      const P block_j = sel(same, i_stays | ~j_stays, swap);
+      ex[i] &= ~block_i;
+      ex[j] &= ~block_j;
     }
 
   // ---- execute_navigation (:615-618): interact(), sequential in agent order ---
   // decision phase + one bit-field insert per item (utils/interact.py:4-75)
+  // arglist.play (uniform): a merge is put straight onto the counter (:44-47), a fresh food is
+  // put DOWN on a Cutboard (:52) and chopped where it lies by an empty-handed press (:66-67)
+  const P play = p_of(PM == 2 ? R.play != 0 : PM == 1);
 #pragma unroll
   for (int a = 0; a < A; a++) {
-    const bool acting = ex[a] && act[a] != OC_ACT_NOOP;  // blocked -> (0,0) (:610-612); interact.py:12
+    const P acting = ex[a] & moving[a];  // blocked -> (0,0) (:610-612); interact.py:12
     // the agent's own cell has not changed since the proposal phase (only its own interact()
     // moves it), so the target cell and its tile type computed there still hold
     const int pa = e.ap[a];
-    const int tp = tgt_p[a], ct = tgt_ct[a];
-    const bool holding = e.ahp[a] != 0;
+    const int tp = tgt_p[a];
+    const P holding = p_nz(e.ahp[a]);
     const int hold_code = (a + 1) << 12;
     // the held Object (items with holder == a) and the unheld Object on the target cell, as
     // ORs of their item words with bit 8 turned into "a food that is still fresh"
     int held_or = 0, tgt_or = 0;
-    bool mine[M], tgt[M];
+    P mine[M], tgt[M];
 #pragma unroll
     for (int i = 0; i < M; i++) {
       const int w = e.iw[i];
       const int u = item_type(L, i) != OC_PLATE ? (w ^ IW_CHOP) : w;  // uniform choice; a Plate is never chopped
-      mine[i] = (w & IW_HOLD) == hold_code;
-      tgt[i] = (w & (IW_HOLD | IW_POS)) == tp;                         // unheld and on the target cell
-      held_or |= mine[i] ? u : 0;
-      tgt_or |= tgt[i] ? u : 0;
+      mine[i] = p_eq(w & IW_HOLD, hold_code);
+      tgt[i] = p_eq(w & (IW_HOLD | IW_POS), tp);                       // unheld and on the target cell
+      held_or |= mine[i] & u;
+      tgt_or |= tgt[i] & u;
     }
-    const bool tgt_any = tgt_or != 0;                                   // tset of an item is never empty
-    bool held_multi;                                                    // > 1 content
+    const P tgt_any = p_nz(tgt_or);                                     // tset of an item is never empty
+    P held_multi;                                                       // > 1 content
     if constexpr (DUP) {   // counts: two of one type are two contents
       int nm = 0;
 #pragma unroll
-      for (int i = 0; i < M; i++) nm += mine[i] ? 1 : 0;
-      held_multi = nm > 1;
+      for (int i = 0; i < M; i++) nm -= mine[i];
+      held_multi = p_gt_i(nm, 1);
     } else {
-      held_multi = (held_or & IW_TSET & ((held_or & IW_TSET) - (1 << 24))) != 0;
+      held_multi = p_nz(held_or & IW_TSET & ((held_or & IW_TSET) - (1 << 24)));
     }
-    const bool held_fresh = (held_or & IW_CHOP) != 0;
-    const bool any_fresh = ((held_or | tgt_or) & IW_CHOP) != 0;
-    const bool two_plates = ((held_or & tgt_or) & sig_of_type<DUP>(OC_PLATE)) != 0;
-    const bool nf = acting && ct != OC_FLOOR;
-    const bool do_move = acting && ct == OC_FLOOR;                       // interact.py:19-20
-    const bool at_deliv = ct == OC_DELIVERY;
-    const bool do_deliver = nf && holding && at_deliv && held_multi && !held_fresh;   // :25-30, core.py:232-237
-    const bool mergeable = !two_plates && !any_fresh;                                   // core.py:240-257
-    const bool do_merge = nf && holding && !at_deliv && tgt_any && mergeable;         // :33-46
-    // arglist.play (uniform): a merge is put straight onto the counter (:44-47), a fresh food is
-    // put DOWN on a Cutboard (:52) and chopped where it lies by an empty-handed press (:66-67)
-    const bool play = PM == 2 ? R.play != 0 : PM == 1;
-    const bool chop_here = ct == OC_CUTBOARD && !held_multi && held_fresh && !play;   // :52
-    const bool do_chop = nf && holding && !at_deliv && !tgt_any && chop_here;         // :52-54
-    const bool do_drop = nf && holding && !at_deliv && !tgt_any && !chop_here;        // :56-57
-    const bool chop_there = nf && !holding && !at_deliv && tgt_any && play && ct == OC_CUTBOARD &&
-                            (tgt_or & IW_CHOP) != 0;                                  // :66-67 (a fresh food is always alone)
-    const bool do_pick = nf && !holding && !at_deliv && tgt_any && !chop_there &&
-                         !((R.allergic >> a) & 1);                                    // :62-71, agent.py:296-298
-    const bool put = do_deliver || do_drop || (do_merge && play);
-    const bool take = (do_merge && !play) || do_pick;
-    const int newg = min(holding ? e.ahp[a] - 1 : 7, igrp(tgt_or));  // only used when `take` (then tgt_any)
+    const P held_fresh = p_bit(held_or, 8);
+    const P any_fresh = p_bit(held_or | tgt_or, 8);
+    const P two_plates = p_nz((held_or & tgt_or) & sig_of_type<DUP>(OC_PLATE));
+    const P at_deliv = t_deliv[a];
+    const P nf = acting & t_nonfloor[a];
+    const P do_move = acting & ~t_nonfloor[a];                                        // interact.py:19-20
+    const P nfh = nf & holding & ~at_deliv, nfe = nf & ~holding & ~at_deliv;
+    const P do_deliver = nf & holding & at_deliv & held_multi & ~held_fresh;          // :25-30, core.py:232-237
+    const P mergeable = ~(two_plates | any_fresh);                                    // core.py:240-257
+    const P do_merge = nfh & tgt_any & mergeable;                                     // :33-46
+    const P chop_here = t_cutb[a] & ~held_multi & held_fresh & ~play;                 // :52
+    const P do_chop = nfh & ~tgt_any & chop_here;                                     // :52-54
+    const P do_drop = nfh & ~tgt_any & ~chop_here;                                    // :56-57
+    const P chop_there = nfe & tgt_any & play & t_cutb[a] & p_bit(tgt_or, 8);         // :66-67 (a fresh food is always alone)
+    const P do_pick = nfe & tgt_any & ~chop_there & p_of(!((R.allergic >> a) & 1));   // :62-71, agent.py:296-298
+    const P put = do_deliver | do_drop | (do_merge & play);
+    const P take = (do_merge & ~play) | do_pick;
+    const int newg = min(sel(holding, e.ahp[a] - 1, 7), igrp(tgt_or));  // only used when `take` (then tgt_any)
     // the merged Object: smallest item id as group, re-inserted under a new name = last in
     // world order (world.py:236-237), union of the type sets
     int objf;
@@ -880,14 +938,14 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
 #pragma unroll
       for (int j = 0; j < MAX_NAMES; j++)
         if (j < (int)L.nnames()) {   // uniform
-          const bool hit = (newsig >> 24) == (int)L.name_sig(j);
+          const P hit = p_eq(newsig >> 24, (int)L.name_sig(j));
           const int sh = 4 * (j & 7);
           const int cur = (e.kn[j >> 3] >> sh) & 15;
-          kf = hit ? cur : kf;
-          const bool enter = hit && cur == 0;   // first Object of this name this episode: the key is created now
-          e.kn[j >> 3] |= (enter && do_merge) ? ((seq4 + 1) << sh) : 0;
+          kf = sel(hit, cur, kf);
+          const P enter = hit & p_z(cur);   // first Object of this name this episode: the key is created now
+          e.kn[j >> 3] |= enter & do_merge & ((seq4 + 1) << sh);
         }
-      const int kseq = kf ? kf - 1 : seq4;
+      const int kseq = sel(p_nz(kf), kf - 1, seq4);
       objf = newsig | (newg << 9) | (((kseq << 4) | seq4) << 16);
     } else {
       objf = ((held_or | tgt_or) & IW_TSET) | (newg << 9) | ((M + e.mctr) << 16);
@@ -900,37 +958,37 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
       // Only reachable when another agent stands on this agent's cell (the 3-agent overlap
       // quirk of check_collisions) while this one merges: one ballot skips the item scan for
       // the whole wave in every other step.
-      bool shared = false;
+      P shared = 0;
 #pragma unroll
       for (int b = 0; b < A; b++)
-        if (b != a) shared |= e.ap[b] == pa;
-      if (__ballot(shared && do_merge) != 0) {
-        bool alias = false;
+        if (b != a) shared |= p_eq(e.ap[b], pa);
+      if (__ballot((shared & do_merge) != 0) != 0) {
+        P alias = 0;
 #pragma unroll
         for (int j = 0; j < M; j++) {
           const int w = e.iw[j];
-          alias |= (w & IW_HOLD) != 0 && (w & IW_HOLD) != hold_code && ipos(w) == pa &&
-                   ((w ^ held_or) & TS<DUP>) == 0 && (w & IW_SEQ) > (held_or & IW_SEQ);
+          alias |= p_nz(w & IW_HOLD) & p_ne(w & IW_HOLD, hold_code) & p_eq(ipos(w), pa) &
+                   p_z((w ^ held_or) & TS<DUP>) & p_gt_i(w & IW_SEQ, held_or & IW_SEQ);
         }
-        if (shared && do_merge && alias) e.err |= OC_ERR_ALIAS;
+        e.err |= shared & do_merge & alias & OC_ERR_ALIAS;
       }
     }
     // held items: cell <- target (move / put down), holder <- none (put down), object
     // fields (merge), chopped (chop); target-cell items: cell <- agent, holder <- agent
     // (merge / pick up), object fields (merge)
-    const int mask_m = ((do_move || put) ? IW_POS : 0) | (put ? IW_HOLD : 0) | (do_merge ? OBJ<DUP> : 0) |
-                       (do_chop ? IW_CHOP : 0);
-    const int mask_t = (take ? (IW_POS | IW_HOLD) : 0) | (do_merge ? OBJ<DUP> : 0) | (chop_there ? IW_CHOP : 0);
+    const int mask_m = ((do_move | put) & IW_POS) | (put & IW_HOLD) | (do_merge & OBJ<DUP>) | (do_chop & IW_CHOP);
+    const int mask_t = (take & (IW_POS | IW_HOLD)) | (do_merge & OBJ<DUP>) | (chop_there & IW_CHOP);
     const int val_m = tp | IW_CHOP | objf;
     const int val_t = pa | hold_code | objf | IW_CHOP;
 #pragma unroll
     for (int i = 0; i < M; i++) {
-      const int sel = mine[i] ? mask_m : (tgt[i] ? mask_t : 0);
-      e.iw[i] = bfi(sel, mine[i] ? val_m : val_t, e.iw[i]);
+      // (an item is held by this agent or lies unheld on the target cell, never both)
+      const int selm = (mine[i] & mask_m) | (tgt[i] & mask_t);
+      e.iw[i] = bfi(selm, sel(mine[i], val_m, val_t), e.iw[i]);
     }
-    e.ap[a] = do_move ? tp : pa;  // agent.py:311-314
-    e.ahp[a] = put ? 0 : (take ? newg + 1 : e.ahp[a]);
-    e.mctr += do_merge ? 1 : 0;
+    e.ap[a] = sel(do_move, tp, pa);  // agent.py:311-314
+    e.ahp[a] = sel(take, newg + 1, e.ahp[a]) & ~put;
+    e.mctr -= do_merge;
   }
 
   // ---- calculate_reward_shaping (:272-397): the position-only distance lookups go out now ----
@@ -967,19 +1025,19 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
   // by construction (mergeable() required it).
   const int d0 = (int)L.deliv_pos(0);  // first Delivery tile only (:259,:402)
   int present = 0, at_delivery = 0;
-  bool rep_ok[M];   // item i represents its Object (group == i) and the Object is all-chopped
+  P rep_ok[M];   // item i represents its Object (group == i) and the Object is all-chopped
 #pragma unroll
   for (int i = 0; i < M; i++) {
     const int w = e.iw[i];
-    const bool rep = (w & IW_GRP) == (i << 9);
+    const P rep = p_eq(w & IW_GRP, i << 9);
     // a lone fresh food is the only Object that is not all-chopped
-    const bool lone_fresh =
-        (int)(item_type(L, i) != OC_PLATE) & (int)((w & (TS<DUP> | IW_CHOP)) == sig_of_type<DUP>(item_type(L, i)));
-    rep_ok[i] = (int)rep & (int)!lone_fresh;
+    const P lone_fresh = item_type(L, i) != OC_PLATE   // uniform
+                             ? p_eq(w & (TS<DUP> | IW_CHOP), sig_of_type<DUP>(item_type(L, i))) : 0;
+    rep_ok[i] = rep & ~lone_fresh;
     if constexpr (!DUP) {
-      const int b = rep_ok[i] ? (1 << itset(w)) : 0;
+      const int b = rep_ok[i] & (1 << itset(w));
       present |= b;
-      at_delivery |= ipos(w) == d0 ? b : 0;
+      at_delivery |= p_eq(ipos(w), d0) & b;
     }
   }
   int cnt_mask = 0, del_mask = 0, newly;
@@ -991,32 +1049,30 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
     for (int g = 0; g < MAX_GOALS; g++)
       if (g < (int)L.ngoal()) {  // uniform
         int cnt = 0;
-        bool hasd = false;
-        bool m[M];
+        P hasd = 0;
+        P m[M];
 #pragma unroll
         for (int i = 0; i < M; i++) {
-          m[i] = (int)rep_ok[i] & (int)((e.iw[i] & TS<true>) == ((int)L.goal_sig(g) << 24));
-          bool seen = false;
+          m[i] = rep_ok[i] & p_eq(e.iw[i] & TS<true>, (int)L.goal_sig(g) << 24);
+          P seen = 0;
 #pragma unroll
-          for (int j = 0; j < i; j++) seen |= (int)m[j] & (int)(ipos(e.iw[j]) == ipos(e.iw[i]));
-          cnt += ((int)m[i] & (int)!seen);
-          hasd |= (int)m[i] & (int)(ipos(e.iw[i]) == d0);
+          for (int j = 0; j < i; j++) seen |= m[j] & p_eq(ipos(e.iw[j]), ipos(e.iw[i]));
+          cnt -= m[i] & ~seen;
+          hasd |= m[i] & p_eq(ipos(e.iw[i]), d0);
         }
         cnt = min(cnt, 3);
         const int old = (e.goalcnt >> (2 * g)) & 3;
-        rose |= cnt > old ? (int)L.goal_nd(g) : 0;
+        rose |= p_gt_i(cnt, old) & (int)L.goal_nd(g);
         cnt_mask |= cnt << (2 * g);
-        del_mask |= hasd ? (int)L.goal_dl(g) : 0;
+        del_mask |= hasd & (int)L.goal_dl(g);
       }
     newly = rose;
   } else {
 #pragma unroll
     for (int g = 0; g < MAX_GOALS; g++) {
       if (g < (int)L.ngoal()) {  // uniform
-        const bool has = (present >> L.goal_tset(g)) & 1;
-        const bool hasd = (at_delivery >> L.goal_tset(g)) & 1;
-        cnt_mask |= has ? (int)L.goal_nd(g) : 0;
-        del_mask |= hasd ? (int)L.goal_dl(g) : 0;
+        cnt_mask |= p_bit(present, L.goal_tset(g)) & (int)L.goal_nd(g);
+        del_mask |= p_bit(at_delivery, L.goal_tset(g)) & (int)L.goal_dl(g);
       }
     }
     newly = cnt_mask & ~e.goalcnt;  // goal count rose above goal_objects_count (:408-415)
@@ -1024,10 +1080,10 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
   reward = __popc(newly) + 3 * __popc(del_mask);  // Deliver pays +3 every step (:400-406)
   e.completed |= newly | del_mask;
   e.goalcnt = cnt_mask;
-  const bool timeout = R.T != 0 && e.t >= R.T;  // checked first (:245-249)
-  const bool all_delivered = del_mask == (int)L.deliver_mask();
-  done = (timeout || all_delivered) ? 1 : 0;
-  success = (!timeout && all_delivered) ? 1 : 0;
+  const P timeout = R.T != 0 ? p_ge_u((unsigned)e.t, (unsigned)R.T) : 0;  // checked first (:245-249)
+  const P all_delivered = p_eq(del_mask, (int)L.deliver_mask());
+  done = (timeout | all_delivered) & 1;
+  success = (~timeout & all_delivered) & 1;
 
   // ---- calculate_reward_shaping for sim agents 0 and 1 (:272-397): the rest of the inputs ----
   sin.completed = e.completed;
@@ -1040,15 +1096,14 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
         bool cand[M];
 #pragma unroll
         for (int i = 0; i < M; i++)
-          cand[i] = (int)rep_ok[i] & (int)((e.iw[i] & TS<true>) == ((int)L.del_sig(k) << 24));
+          cand[i] = (rep_ok[i] & p_eq(e.iw[i] & TS<true>, (int)L.del_sig(k) << 24)) != 0;
         sin.del_p[k] = pyset_first<M>(L, probe, e.iw, cand, sin.del_has[k]);
       } else {
 #pragma unroll
         for (int i = 0; i < M; i++) {
-          // `&`, not `&&`: the short-circuit form became an exec-masked region per item
-          const bool ok = (int)rep_ok[i] & (int)((e.iw[i] & IW_TSET) == ((int)L.del_tset(k) << 24));
-          sin.del_has[k] |= ok;
-          sin.del_p[k] = ok ? ipos(e.iw[i]) : sin.del_p[k];
+          const P ok = rep_ok[i] & p_eq(e.iw[i] & IW_TSET, (int)L.del_tset(k) << 24);
+          sin.del_has[k] |= ok & 1;
+          sin.del_p[k] = sel(ok, ipos(e.iw[i]), sin.del_p[k]);
         }
       }
     }
@@ -1164,13 +1219,13 @@ struct MetricsSlot {
   __device__ __forceinline__ void add(bool has_metrics, bool valid, int done, int success, int reward,
                                       int completed_bits, bool err) {
     if (!has_metrics) return;  // uniform
-    const bool fin = valid && done;
+    // (P words, see `hide`: valid / done / success / err combine on the vector unit)
+    const P ok = hide(valid ? -1 : 0), fin = ok & -done;
     // word A: reward (<= 32 + 3 * MAX_DELS < 64 -> 12-bit sum) | completed subtasks of a finished
     // episode (<= OC_MAX_SUBTASKS = 32 per lane, 64 lanes -> a 12-bit sum)
     // word B: valid | done | success | error, 7 bits each (a count up to 64)
-    const int a = (valid ? reward : 0) | ((fin ? __popc(completed_bits) : 0) << 12);
-    const int b = (valid ? 1 : 0) | ((fin ? 1 : 0) << 7) | (((valid && success) ? 1 : 0) << 14) |
-                  (((valid && err) ? 1 : 0) << 21);
+    const int a = (ok & reward) | ((fin & __popc(completed_bits)) << 12);
+    const int b = (ok & 1) | (fin & (1 << 7)) | (ok & -success & (1 << 14)) | (ok & hide(err ? -1 : 0) & (1 << 21));
     const unsigned ta = (unsigned)__builtin_amdgcn_readlane(wave_sum_lane63(a), 63);
     const unsigned tb = (unsigned)__builtin_amdgcn_readlane(wave_sum_lane63(b), 63);
     // lane k picks counter k out of the two totals: a per-lane (word, offset, width) from
@@ -1372,7 +1427,12 @@ __device__ __forceinline__ void step_body(int32_t *const state_, const int32_t *
     if constexpr (D_STATE) {
       Out(p.reward, p.n, 1, i).st(0, reward);
       Out(p.done, p.n, 1, i).st(0, done);
-      if (done && auto_reset_) {
+      if (L.nscatter() == 0) {   // uniform: a fixed level -- the fresh episode is a constant, selected word by word
+        pack<A, M, DUP>(e, w);
+        const P fresh = -done & p_of(auto_reset_);
+#pragma unroll
+        for (int r = 0; r < WS; r++) w[r] = sel(fresh, L.init_words(r), w[r]);
+      } else if (done && auto_reset_) {
 #pragma unroll
         for (int r = 0; r < WS; r++) w[r] = L.init_words(r);
         place_items<A, M, WS>(L, tb, p.placement, p.rng, p.n, i, w);
@@ -1815,24 +1875,26 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     const int cfg_can_move = XO ? p.cfg.can_move_mask : 3, cfg_ego_idx = XO ? p.cfg.ego_agent_idx : 0;
     const int cfg_blind = XO ? p.cfg.obs.blind_mask : 0;
     const unsigned NC = (unsigned)p.cfg.obs.num_comm;
+    // (per-lane predicates are P words, 0 / -1, see `hide`; the cfg_* tests are wave-uniform)
     const bool ego_talks = cfg_comm_on, alt_talks = cfg_comm_on && !cfg_ego_led;
-    const bool bad_cm = (ego_talks && (unsigned)ego_cm >= NC) | (alt_talks && (unsigned)alt_cm >= NC);
-    const int c0 = (ego_talks && (unsigned)ego_cm < NC) ? ego_cm : -1;
-    const int c1 = (alt_talks && (unsigned)alt_cm < NC) ? alt_cm : -1;
+    const P ego_cm_bad = p_ge_u((unsigned)ego_cm, NC), alt_cm_bad = p_ge_u((unsigned)alt_cm, NC);
+    const P bad_cm = (p_of(ego_talks) & ego_cm_bad) | (p_of(alt_talks) & alt_cm_bad);
+    const int c0 = ego_talks ? (ego_cm | ego_cm_bad) : -1;    // the index, or -1 = nothing sent
+    const int c1 = alt_talks ? (alt_cm | alt_cm_bad) : -1;
     if constexpr (D_STATE) {
       cm.st(0, c0);
       cm.st(1, c1);
     }
     // NAV_ACTIONS lookup (both indices, moved or not: :248) + CAN_MOVE gating + ego_agent_idx
     // (:250-262); NAV_ACTIONS[idx] raises for idx > 3: flagged, executed as (0, 0)
-    const bool bad_mv = ((unsigned)ego_mv > 3u) | ((unsigned)alt_mv > 3u);
-    const int em = ((cfg_can_move & 1) && (unsigned)ego_mv <= 3u) ? ego_mv : OC_ACT_NOOP;
-    const int am = ((cfg_can_move & 2) && (unsigned)alt_mv <= 3u) ? alt_mv : OC_ACT_NOOP;
+    const P bad_mv = p_gt_u((unsigned)ego_mv, 3u) | p_gt_u((unsigned)alt_mv, 3u);
+    const int em = (cfg_can_move & 1) ? (int)min((unsigned)ego_mv, 4u) : OC_ACT_NOOP;   // (> 3 -> 4 = OC_ACT_NOOP)
+    const int am = (cfg_can_move & 2) ? (int)min((unsigned)alt_mv, 4u) : OC_ACT_NOOP;
     int act[A];
     act[0] = cfg_ego_idx == 0 ? em : am;
     act[1] = cfg_ego_idx == 0 ? am : em;
     const int err_before = e.err;
-    e.err |= (bad_mv | bad_cm) ? OC_ERR_ACTION : 0;
+    e.err |= (bad_mv | bad_cm) & OC_ERR_ACTION;
     ShapeIn<2> sin;
     ShapeLoads<2> sld;
     // (the plain variant is only launched for play == 0; the general one reads the flag)
@@ -1846,7 +1908,16 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
 #endif
     }
     if constexpr (DUTY != DUTY_SHAPE) {   // (the shaping reads the pre-reset env only, through `sin`)
-      if (done && p.auto_reset) {
+      if ((DUTY & (DUTY_OBS0 | DUTY_OBS1)) == 0 && L.nscatter() == 0) {
+        // the state wave of a split launch, a fixed level (uniform; compile-time in specialised
+        // builds): the fresh episode is a constant, selected word by word -- a branch on `done` is
+        // v_cmp -> s_and_saveexec, a scalar read of a vector-written mask (see `hide`).  (A wave that
+        // goes on to the observations keeps the branch: it would have to unpack the words again.)
+        pack<A, M, DUP>(e, w);
+        const P fresh = -done & p_of(p.auto_reset != 0);
+#pragma unroll
+        for (int r = 0; r < WS; r++) w[r] = sel(fresh, L.init_words(r), w[r]);
+      } else if (done && p.auto_reset) {
 #pragma unroll
         for (int r = 0; r < WS; r++) w[r] = L.init_words(r);
         if constexpr (SPLIT) {   // every wave draws the same cells from its copy of the stream's word
@@ -1993,10 +2064,15 @@ __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const
       if (role == 0) OC_BODY(DUTY_STATE | DUTY_OBS0);
       else OC_BODY(DUTY_SHAPE | DUTY_OBS1);
     } else {
-      if (role == 0) OC_BODY(DUTY_STATE);
-      else if (role == 1) OC_BODY(DUTY_SHAPE);
-      else if (role == 2) OC_BODY(DUTY_OBS0);
-      else OC_BODY(DUTY_OBS1);
+      // The waves of a workgroup do not start together: waves 2 and 3 came ~240 cycles after waves
+      // 0 and 1 in every stamped run, and all four leave the barrier behind the state loads at the
+      // time of the LAST one.  The two long arms (the observations: ~30 row stores each) therefore
+      // go to the early waves, which at least issue their prologue under that wait, and the two
+      // short arms to the late ones.
+      if (role == 0) OC_BODY(DUTY_OBS0);
+      else if (role == 1) OC_BODY(DUTY_OBS1);
+      else if (role == 2) OC_BODY(DUTY_STATE);
+      else OC_BODY(DUTY_SHAPE);
     }
   }
 #undef OC_BODY

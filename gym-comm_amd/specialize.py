@@ -82,7 +82,7 @@ def _source_digest():
 
 
 # build variants of a specialised library beside the product one (measurement only)
-VARIANT_FLAGS = {"": [], "timeline": ["-DOC_TIMELINE"]}    # include/oc_hip.h: oc_timeline_begin
+VARIANT_FLAGS = {"": [], "timeline": ["-DOC_TIMELINE=1"], "timeline-drain": ["-DOC_TIMELINE=2"]}    # include/oc_hip.h: oc_timeline_begin
 
 
 def spec_key(blob, geometry=True, variant="") -> str:
@@ -158,8 +158,8 @@ def load_for(blob, mode="auto", verbose=False):
         mode = "structure"          # (measurements / a test-suite pass on the structure libraries)
     if mode is False:
         return "generic", _lib.load()
-    if mode == "timeline":          # measurement flavour of the level library (bench.py --decompose)
-        path = ensure(blob, verbose=verbose, geometry=True, variant="timeline")
+    if mode in ("timeline", "timeline-drain"):   # measurement flavours of the level library (bench.py --decompose)
+        path = ensure(blob, verbose=verbose, geometry=True, variant=mode)
         if path is None:
             raise _lib.OcError("no cached timeline library for this level and hipcc is unavailable")
         return "spec", _lib.load(path)

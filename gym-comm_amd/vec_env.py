@@ -26,6 +26,9 @@ Partners
   ``TorchPolicyPartner``   any ``torch.nn.Module`` mapping the observation dict to (move logits,
                            comm logits) -- the batched stand-in for pantheonrl's
                            ``OnPolicyAgent.get_action`` / ``update`` (agents.py:112-194);
+  ``RecurrentPolicyPartner``  a STATEFUL torch policy (per-env recurrent state, ``episode_start``
+                           masks, log-probs / values, a graph-capturable ``RolloutSink``) -- what
+                           the reference seats there: ``OnPolicyAgent(RecurrentPPO(...))``;
   ``FusedMLPPartner``      an ``MLPPolicy`` (64 tanh units) as ONE launch of the hand-written MFMA
                            policy kernel (include/oc_policy.h), ego and partner in the same launch;
   any callable ``partner(obs_dict) -> [n, 2]`` still works (slow path).
@@ -42,6 +45,7 @@ policies that live on the GPU; the numpy API packs a step's arrays with one laun
 import contextlib
 import ctypes
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -209,6 +213,183 @@ class TorchPolicyPartner:
             self.on_update(rewards, dones)
 
 
+class RolloutSink:
+    """What pantheonrl's ``OnPolicyAgent`` keeps per step in its rollout buffer -- ``buf.add(obs,
+    action, [0], episode_start, value, log_prob)`` in ``get_action`` and ``buf.rewards[pos - 1] +=
+    reward`` in ``update`` (pantheonrl/common/agents.py:112-214) -- for a whole batch, in
+    PREALLOCATED ``[n_steps][...][n]`` device tensors whose write position is itself a device scalar.
+    Every write is an ``index_copy_`` / ``index_add_`` on that scalar, so recording neither
+    synchronises nor changes shape: it can sit inside a captured hipGraph (a learner's hook that runs
+    host code per step cannot).  ``full()`` / ``steps()`` read the counter (one sync, when asked);
+    ``reset()`` starts the next rollout.  Past ``n_steps`` the position wraps (a ring)."""
+
+    def __init__(self, n_steps, n, rows, device="cuda", obs_dtype=torch.int32):
+        dev = torch.device(device)
+        T = self.n_steps = int(n_steps)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.obs = z((T, int(rows), n), obs_dtype)       # the viewer's [F][n] rows as they lie
+        self.timestep = z((T, n), torch.float64)
+        self.actions = z((T, 2, n), torch.int32)         # (move, comm)
+        self.log_probs = z((T, n), torch.float32)
+        self.values = z((T, n), torch.float32)
+        self.rewards = z((T, n), torch.float64)
+        self.episode_starts = z((T, n), torch.float32)
+        self.dones = z((T, n), torch.int32)
+        self.pos = z((1,), torch.int64)                  # next slot
+        self.last = z((1,), torch.int64)                 # slot of the most recent add()
+        self.count = z((1,), torch.int64)                # adds since reset()
+
+    def add(self, rows, timestep, move, comm, log_prob, value, episode_start):
+        i = self.pos
+        self.obs.index_copy_(0, i, rows.unsqueeze(0))
+        self.timestep.index_copy_(0, i, timestep.unsqueeze(0))
+        self.actions.index_copy_(0, i, torch.stack([move, comm]).to(torch.int32).unsqueeze(0))
+        self.log_probs.index_copy_(0, i, log_prob.to(torch.float32).unsqueeze(0))
+        if value is not None:
+            self.values.index_copy_(0, i, value.reshape(1, -1).to(torch.float32))
+        self.episode_starts.index_copy_(0, i, episode_start.to(torch.float32).unsqueeze(0))
+        self.rewards.index_fill_(0, i, 0.0)              # buf.add(..., [0], ...): update() adds
+        self.last.copy_(i)
+        self.pos.add_(1).remainder_(self.n_steps)
+        self.count.add_(1)
+
+    def add_reward(self, rewards, dones):
+        """``update(reward, done)`` of the step the most recent ``add`` belongs to."""
+        self.rewards.index_add_(0, self.last, rewards.to(torch.float64).unsqueeze(0))
+        self.dones.index_copy_(0, self.last, dones.to(torch.int32).unsqueeze(0))
+
+    def steps(self):
+        return int(self.count.item())
+
+    def full(self):
+        return self.steps() >= self.n_steps
+
+    def reset(self):
+        self.pos.zero_()
+        self.last.zero_()
+        self.count.zero_()
+
+    def get_state(self):
+        return self.pos.clone(), self.last.clone(), self.count.clone()
+
+    def set_state(self, st):
+        self.pos.copy_(st[0])
+        self.last.copy_(st[1])
+        self.count.copy_(st[2])
+
+
+class RecurrentPolicyPartner:
+    """A STATEFUL torch policy in the partner (or ego) seat: the batched form of what the
+    reference seats there -- ``OnPolicyAgent(RecurrentPPO('MultiInputPolicy', ...))``
+    (trainer.py:92-112; pantheonrl/common/agents.py:112-214; sb3_contrib's recurrent policies
+    carry LSTM states per env and reset them where ``episode_starts`` is set).
+
+        policy(obs, state, episode_start) -> (move_logits, comm_logits, new_state[, value])
+
+    ``obs``: the viewer's ``ObsView`` ([n, k] keys, ``rows`` [F][n], ``timestep``); ``state``: a
+    tuple of ``[n, ...]`` tensors OWNED BY THE PARTNER (updated in place, so a captured graph keeps
+    their addresses); ``episode_start``: float32 [n], 1 where the env's previous step returned done
+    (the step kernel's ``done`` row, handed over by ``update``) and for every env on the first step
+    after a reset -- SB3's ``_last_episode_starts``.  With ``mask_state`` (default) the partner
+    itself puts the initial state back into the rows of starting envs before the call, so a policy
+    that ignores ``episode_start`` is still correct.  Logits are ``[n, k]``, or ``[k, n]`` when
+    ``policy.feature_major``; ``value`` is optional ([n] or [n, 1]).
+
+    Actions: argmax, or a categorical sample (Gumbel-max on the default CUDA generator:
+    hipGraph-capturable), written into the kernel's action rows; their log-probability under the
+    policy is computed either way.  ``sink`` (a ``RolloutSink``) records (obs, action, log_prob,
+    value, episode_start) at ``act_into`` and (reward, done) at ``update`` WITHOUT leaving the
+    device or the graph; ``on_update(rewards, dones)`` is the host-side learner hook (it switches
+    graph capture off, as for ``TorchPolicyPartner``)."""
+
+    def __init__(self, policy, state, sample=True, seed=None, device="cuda", sink=None, on_update=None,
+                 mask_state=True):
+        self.policy = policy
+        self.sample = bool(sample)
+        self.device = torch.device(device)
+        self.sink = sink
+        self.on_update = on_update
+        self.mask_state = bool(mask_state)
+        self.graph_safe = on_update is None
+        state = tuple(state) if isinstance(state, (tuple, list)) else (state,)
+        self.initial = tuple(s.detach().clone().to(self.device) for s in state)
+        self.state = tuple(s.clone() for s in self.initial)
+        n = self.state[0].shape[0]
+        self.episode_start = torch.ones(n, dtype=torch.float32, device=self.device)
+        self.log_prob = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.value = torch.zeros(n, dtype=torch.float32, device=self.device)
+        if seed is not None:
+            with torch.cuda.device(self.device):
+                torch.cuda.manual_seed(int(seed))
+
+    def reset(self):
+        """A fresh rollout: every env starts an episode (called by ``reset_tensors``)."""
+        self.episode_start.fill_(1.0)
+        for s, s0 in zip(self.state, self.initial):
+            s.copy_(s0)
+
+    def _pick(self, logits, dim):
+        if self.sample:
+            logits = logits - torch.empty_like(logits).exponential_().log_()
+        return logits.argmax(dim=dim)
+
+    @torch.no_grad()
+    def act_into(self, obs, move_row, comm_row):
+        es = self.episode_start
+        if self.mask_state:
+            for s, s0 in zip(self.state, self.initial):
+                s.copy_(torch.where(es.view((-1,) + (1,) * (s.dim() - 1)) > 0, s0, s))
+        out = self.policy(obs, self.state, es)
+        mv, cm, new_state = out[0], out[1], out[2]
+        value = out[3] if len(out) > 3 else None
+        dim = 0 if getattr(self.policy, "feature_major", False) else 1
+        a_mv, a_cm = self._pick(mv, dim), self._pick(cm, dim)
+        lp = (torch.log_softmax(mv.float(), dim=dim).gather(dim, a_mv.unsqueeze(dim)).squeeze(dim)
+              + torch.log_softmax(cm.float(), dim=dim).gather(dim, a_cm.unsqueeze(dim)).squeeze(dim))
+        move_row.copy_(a_mv)
+        comm_row.copy_(a_cm)
+        self.log_prob.copy_(lp)
+        if value is not None:
+            self.value.copy_(value.reshape(-1))
+        new_state = tuple(new_state) if isinstance(new_state, (tuple, list)) else (new_state,)
+        for s, ns in zip(self.state, new_state):
+            s.copy_(ns)
+        if self.sink is not None:
+            rows = getattr(obs, "rows", None)
+            if rows is None:
+                rows = torch.cat([obs[k].reshape(obs[k].shape[0], -1) for k in OBS_KEYS], dim=1).T
+            ts = obs.timestep if getattr(obs, "timestep", None) is not None else obs["timestep"].reshape(-1)
+            self.sink.add(rows, ts, move_row, comm_row, lp, value, es)
+
+    def __call__(self, obs):
+        n = self.episode_start.numel()
+        out = torch.empty((2, n), dtype=torch.int32, device=self.device)
+        self.act_into(obs, out[0], out[1])
+        return out.T
+
+    def update(self, rewards, dones):
+        """pantheonrl's ``Agent.update(reward, done)`` for the batch: ``dones`` become the next
+        step's ``episode_start`` (agents.py:207-208), the reward joins the recorded transition."""
+        self.episode_start.copy_(dones)
+        if self.sink is not None:
+            self.sink.add_reward(rewards, dones)
+        if self.on_update is not None:
+            self.on_update(rewards, dones)
+
+    def get_state(self, n=None):
+        return (tuple(s.clone() for s in self.state), self.episode_start.clone(), self.log_prob.clone(),
+                self.value.clone(), None if self.sink is None else self.sink.get_state())
+
+    def set_state(self, st):
+        for s, v in zip(self.state, st[0]):
+            s.copy_(v)
+        self.episode_start.copy_(st[1])
+        self.log_prob.copy_(st[2])
+        self.value.copy_(st[3])
+        if self.sink is not None:
+            self.sink.set_state(st[4])
+
+
 class FusedMLPPartner:
     """An ``MLPPolicy`` in the partner (or ego) seat as ONE launch of the hand-written policy
     kernel (include/oc_policy.h, csrc/oc_policy.hip): both products on the matrix cores
@@ -297,6 +478,20 @@ class FusedMLPPartner:
         if rc:
             raise _lib.OcError("oc_policy_mlp failed (%d): %s" % (rc, first._L.oc_policy_last_error().decode()))
 
+    _PCG_MULT, _PCG_INC = 747796405, 2891336453          # csrc/oc_policy_device.h: pcg32
+    _PCG_MULT_INV = pow(747796405, -1, 1 << 32)
+
+    def rewind_rng(self):
+        """Step both PCG32 streams of every env back by ONE draw (the generator's state update is
+        an invertible affine map mod 2^32): the next evaluation repeats the last one's draw.  How a
+        one-launch closed loop re-primes after a reset without leaving the sequence the two-launch
+        form walks (``ClosedLoop.prime``)."""
+        if self._rng is None or not self.sample:
+            return
+        s = self._rng.to(torch.int64) & 0xFFFFFFFF
+        s = ((s - self._PCG_INC) * self._PCG_MULT_INV) & 0xFFFFFFFF
+        self._rng.copy_(torch.where(s >= (1 << 31), s - (1 << 32), s).to(torch.int32))
+
     def step_policy(self, n):
         """(w1, w2, b2, rng) device addresses for oc_step_opts.policy (the step kernel evaluates
         this policy itself; its result lands in ``self.pairs``)."""
@@ -351,15 +546,33 @@ class ClosedLoop:
             raise ValueError("one_launch needs two FusedMLPPartner of one shape, C <= 4 and a specialised library")
         self.one_launch = (can and venv._b.launch_waves_per_64 == 4) if one_launch is None else bool(one_launch)
         self._primed = False
-        if self.one_launch:     # the first step's pairs: one launch of the policy kernel, outside any graph
-            o0, o1 = venv._obs_tensors(0), venv._obs_tensors(1)
-            FusedMLPPartner.launch([ego, pt], [o0.rows, o1.rows], o0.timestep)
-            self._primed = True
+        self.prime()
+        venv._loops.add(self)       # reset_tensors() re-primes every live loop (weak references)
         if graph:
             for pl in (ego, venv.partner):
                 if pl is not None and not getattr(pl, "graph_safe", False):
                     raise ValueError("%r is not marked graph_safe (stateless, fixed-shape)" % (pl,))
             self.graph = venv._capture(self.enqueue, players=[ego], repeat=self.steps)
+
+    def prime(self):
+        """One-launch closed loop only: ``ego.pairs`` / ``partner.pairs`` hold the NEXT step's actions,
+        computed by the previous step's launch from the observations it wrote.  After anything that
+        rewrites the observations behind the loop's back -- ``reset_tensors()`` above all, which
+        calls this for every live loop -- they must be recomputed from the CURRENT observations (one
+        eager launch of the policy kernel, outside any graph), or the first step after the reset
+        would play actions sampled for the pre-reset state.  Order for a loop built
+        before the first reset: ``closed_loop(...)``, ``reset_tensors()`` (primes), ``step()``..."""
+        if not self.one_launch:
+            return
+        v = self.venv
+        if self._primed:
+            # the pending pairs being replaced consumed one draw of each stream: take it back, so the
+            # re-evaluation on the new observations uses the draw the two-launch form would use next
+            self.ego.rewind_rng()
+            v.partner.rewind_rng()
+        o0, o1 = v._obs_tensors(0), v._obs_tensors(1)
+        FusedMLPPartner.launch([self.ego, v.partner], [o0.rows, o1.rows], o0.timestep)
+        self._primed = True
 
     def enqueue(self):
         v = self.venv
@@ -385,6 +598,11 @@ class ClosedLoop:
             if ego is not None:
                 ego.act_into(v._obs_tensors(0), v._act[0], v._act[1])
             v._partner_and_step(None)
+        # MultiAgentEnv._update_players (multiagentenv.py:186-195): every seated agent hears the
+        # step's reward and done -- inside the captured graph when the player's update() is device work
+        for pl in (ego, pt):
+            if pl is not None and hasattr(pl, "update"):
+                pl.update(v._b.shaped_reward, v._b.done)
         v._version += 1
 
     def step(self):
@@ -425,6 +643,7 @@ class OvercookedVecEnv(_VecEnvBase):
         obs_space, act_space = make_spaces(lv.width, lv.height, lv.num_subtasks, self._b.C)
         super().__init__(num_envs, obs_space, act_space)
         self._fast = self._graph = None
+        self._loops = weakref.WeakSet()                  # live ClosedLoop objects (re-primed by reset_tensors)
         self.partner = partner if partner is not None else RandomPartner(self._b.C, seed, self._b.device)
         self._act = torch.zeros((4, num_envs), dtype=torch.int32, device=self._b.device)
         self._pending = None
@@ -437,6 +656,7 @@ class OvercookedVecEnv(_VecEnvBase):
         self._last_terminal = None
         self._version = 0                                # bumped by every step / reset
         self._env_views = {}                             # env index -> (OvercookedEnvironment view, version)
+        self._env_attrs = {}                             # (env index, name) -> value set by set_attr(indices=...)
         self._use_graph = bool(use_graph) and not self.terminal_obs
         self._ego_pairs = None
         self._act_pinned = None
@@ -490,6 +710,15 @@ class OvercookedVecEnv(_VecEnvBase):
             b.ep_length.zero_()
         b.observe()
         self._version += 1
+        # players with per-episode state start over (a recurrent partner's states and episode_start),
+        # and every live one-launch closed loop recomputes its pending actions from the new observations
+        seen = set()
+        for pl in [self.partner] + [lp.ego for lp in self._loops]:
+            if pl is not None and id(pl) not in seen and hasattr(pl, "reset"):
+                seen.add(id(pl))
+                pl.reset()
+        for lp in self._loops:
+            lp.prime()
         return self._obs_tensors(0)
 
     def closed_loop(self, ego=None, graph=True, steps=1, one_launch=None):
@@ -604,10 +833,16 @@ class OvercookedVecEnv(_VecEnvBase):
                 self._ego_pairs = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=b.device)
             if ego_pairs is None:       # ego rows written by the caller: bring them into the graph's input
                 self._ego_pairs.copy_(self._act[0:2].T)
-            if self._graph is None:     # partner -> fused step, captured once
-                self._graph = self._capture(lambda: self._partner_and_step(self._ego_pairs))
+            if self._graph is None:     # partner -> fused step (-> the partner's update), captured once
+                def one_step():
+                    self._partner_and_step(self._ego_pairs)
+                    if hasattr(self.partner, "update"):
+                        self.partner.update(b.shaped_reward, b.done)
+                self._graph = self._capture(one_step)
             self._graph.replay()
             self._version += 1
+            self._last_terminal = None
+            return self._obs_tensors(0), b.shaped_reward, b.done
         else:
             if self.terminal_obs:
                 self._partner_and_step(ego_pairs, auto_reset=False)
@@ -771,10 +1006,24 @@ class OvercookedVecEnv(_VecEnvBase):
             return [self.base_env(i) for i in idx]
         if attr_name in self._PER_ENV_ATTRS:
             return [getattr(self.base_env(i), attr_name) for i in idx]
-        return [getattr(self, attr_name)] * len(idx)
+        # an attribute set for some envs only (set_attr with indices) lives on those envs' views
+        return [self._env_attrs[(i, attr_name)] if (i, attr_name) in self._env_attrs else getattr(self, attr_name)
+                for i in idx]
 
     def set_attr(self, attr_name, value, indices=None):
-        setattr(self, attr_name, value)
+        """SB3's ``VecEnv.set_attr``: the attribute of the envs in ``indices`` (None = all).  The
+        device state of an env is not settable this way (the per-env views are read-only mirrors):
+        state-derived names raise.  ``indices=None`` sets a batch-level attribute of the VecEnv;
+        a subset is remembered per env and returned by ``get_attr`` for those envs."""
+        if attr_name in self._PER_ENV_ATTRS:
+            raise AttributeError("%r mirrors device state and is read-only" % attr_name)
+        if indices is None:
+            setattr(self, attr_name, value)
+            for key in [k for k in self._env_attrs if k[1] == attr_name]:
+                del self._env_attrs[key]
+            return
+        for i in self._indices(indices):
+            self._env_attrs[(i, attr_name)] = value
 
     _PER_ENV_METHODS = ("render_frame", "render_rgb", "display", "get_agent_names", "__str__")
 

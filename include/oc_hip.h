@@ -260,21 +260,23 @@ OC_API int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, co
  * not at all).  Host only; for reports and tests. */
 OC_API int32_t oc_multi_step_waves(int64_t n, int32_t hint);
 
-/* Measurement hook of the TIMELINE build flavour (the same source compiled with -DOC_TIMELINE;
+/* Measurement hook of the TIMELINE build flavour (the same source compiled with -DOC_TIMELINE=1;
  * gym-comm_amd/specialize.py, variant="timeline"; every other build returns OC_E_BADARG).  In such a
  * build every wave of the step kernels reads the chip-wide constant-rate counter (s_memrealtime,
- * 100 MHz) at its start, after its last instruction and after its last store was acknowledged;
- * the next `count` calls of oc_step / oc_multi_step -- eager or captured into a hipGraph -- each
- * get one record of `records` (DEVICE memory, uint64 [count][4][stride]) into which wave w of the
- * launch (w = workgroup * waves per workgroup + wave, < 4 * ceil(n / 64) <= stride) stores
- *   [0][w] start   [1][w] issue-end   [2][w] drain-end   [3][w] shader-clock cycles (s_memtime) from
- *   start to drain-end: with [2] - [0] it gives the shader clock the wave ran at
- * (plain stores to the wave's own words; a launch with fewer waves leaves the rest untouched, so
- * the caller fills [0] with ~0 and [1..3] with 0 before every run and reduces min / max / max over
- * w).  Per launch, max drain-end - min start is the span with waves on the chip ("kernel-active"),
- * the next launch's min start - max drain-end the launch boundary; bench.py --decompose reports
- * both beside the unchanged headline.  No reference analogue.  records = NULL, count = 0 stops the
- * recording. */
+ * 100 MHz) at its start and after its last instruction (-DOC_TIMELINE=2, variant
+ * "timeline-drain": also after an added wait for its last store); the next `count` calls of
+ * oc_step / oc_multi_step -- eager or captured into a hipGraph -- each get one record of `records`
+ * (DEVICE memory, uint64 [count][4][stride]) into which wave w of the launch (w = workgroup * waves
+ * per workgroup + wave, < 4 * ceil(n / 64) <= stride) stores
+ *   [0][w] start   [1][w] issue-end   [2][w] drain-end (0 unless OC_TIMELINE=2)
+ *   [3][w] shader-clock cycles (s_memtime) from start to the last stamp: against the realtime
+ *          span it gives the shader clock the wave ran at
+ * (write-through stores to the wave's own words; a launch with fewer waves leaves the rest
+ * untouched, so the caller fills [0] with ~0 and [1..3] with 0 before every run and reduces
+ * min / max over w).  Per launch, max issue-end - min start is the span with waves on the chip
+ * ("kernel-active"), the next launch's min start - max issue-end the launch boundary (store drain,
+ * end-of-kernel cache work, command processor, dispatch); bench.py --decompose reports both beside
+ * the unchanged headline.  No reference analogue.  records = NULL, count = 0 stops the recording. */
 OC_API int oc_timeline_begin(uint64_t *records, int64_t count, int64_t stride);
 
 /* Uniform random (move, comm) indices for one player of every env, written straight into two

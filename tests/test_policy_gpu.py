@@ -223,3 +223,46 @@ def test_closed_loop_in_one_launch_equals_policy_kernel_plus_step(n, level, C, o
                 assert torch.equal(getattr(oneg[0]._b, name), getattr(one[0]._b, name)), (k, name)
             assert torch.equal(oneg[1].pairs, one[1].pairs) and torch.equal(oneg[2]._rng, one[2]._rng), k
     assert two[0]._b.read_metrics()["env_steps"] == one[0]._b.read_metrics()["env_steps"] == 9 * n
+    # a reset in mid-run: the one-launch loop's pending pairs were sampled for the
+    # pre-reset observations; reset_tensors() re-primes every live loop from the NEW observations
+    # (with the draw the two-launch form uses next), so the two forms stay bit-identical
+    for v in (two, one, oneg):
+        v[0].reset_tensors()
+    for k in range(6):
+        two[3].step()
+        one[3].step()
+        for name in ("state", "obs", "shaped_reward", "done", "ep_return", "ep_length", "comm"):
+            assert torch.equal(getattr(two[0]._b, name), getattr(one[0]._b, name)), ("after reset", k, name)
+        if k % 3 == 2:
+            oneg[3].step()
+            for name in ("state", "obs", "shaped_reward", "done", "ep_return"):
+                assert torch.equal(getattr(oneg[0]._b, name), getattr(one[0]._b, name)), ("after reset", k, name)
+
+
+def test_closed_loop_built_before_the_first_reset_is_primed_by_it():
+    """``closed_loop()`` before ``reset_tensors()``: the pairs primed from the all-zero observations
+    are replaced by the reset (documented order: closed_loop, reset_tensors, step ...)."""
+    from types import SimpleNamespace
+    from gym_comm_amd.vec_env import FusedMLPPartner, MLPPolicy, OvercookedVecEnv
+    arg = SimpleNamespace(level="open-divider_tomato", num_agents=2, max_num_timesteps=40, ego_config={},
+                          partner_config={}, num_communication=2, communication_on=True, ego_led=False, fow_radius=2)
+    n = 2048
+
+    def make(loop_first):
+        venv = OvercookedVecEnv(arg, n, seed=1)
+        ego = FusedMLPPartner(MLPPolicy(venv._b.S, 2, seed=1).cuda(), sample=True, seed=7)
+        venv.partner = FusedMLPPartner(MLPPolicy(venv._b.S, 2, seed=2).cuda(), sample=True, seed=8)
+        if loop_first:
+            loop = venv.closed_loop(ego, graph=False, one_launch=True)
+            venv.reset_tensors()
+        else:
+            venv.reset_tensors()
+            loop = venv.closed_loop(ego, graph=False, one_launch=True)
+        return venv, loop
+
+    a, b = make(True), make(False)
+    for k in range(5):
+        a[1].step()
+        b[1].step()
+        for name in ("state", "obs", "shaped_reward", "done"):
+            assert torch.equal(getattr(a[0]._b, name), getattr(b[0]._b, name)), (k, name)
