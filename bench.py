@@ -24,9 +24,11 @@ barrier + synchronize on both sides.  Blocks are hipGraph replays; a K shorter t
 ~10 us between two graph launches is not charged to 20 steps.  A HIP event on the launch
 stream separates the replays; ``ms_per_step`` is the MEDIAN block time / K (MAX over ranks):
 a short ``--steps`` gives the steady-state number, not one launch + sync latency.  The wall
-clock over the whole region is reported beside it (``ms_per_step_wall``).  Before the calibration
-and the timed region, 150 ms of untimed replays (on top of the ``--warmup`` steps) let the box
-settle: the first tens of ms of GPU work after host-side idling can run ~10x slow here.
+clock over the whole region is reported beside it (``ms_per_step_wall``; for N > 1 it is the
+value).  The host POLLS the last event instead of blocking on it: a blocked wait on this box
+sometimes returns 50-80 ms after the device has finished (tools/slow_stretch_probe4.py) -- what
+round 2 took for a "slow stretch" of the GPU and hid behind 150 ms of untimed replays.  A short
+untimed settle (``--settle-ms``, 30 ms: the first replays of a freshly instantiated graph) remains.
 
 ``--mode closed-loop`` measures the same kernel with policies in the loop (an ego and a
 partner MLP on the observations, actions sampled on the device, episode statistics; one
@@ -55,7 +57,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WINDOW = 256                # pre-generated action steps, cycled
 MIN_TIMED_MS = 50.0         # GPU time the timed region must cover (reps is derived from it)
-SETTLE_MS = 150.0        # untimed replays before calibration and timing (see main)
+SETTLE_MS = 30.0         # untimed replays before calibration and timing (--settle-ms; see main)
 ELEM = {"int32": 4, "int8": 1, "float32": 4}
 
 
@@ -122,6 +124,8 @@ def parse(argv=None):
                    help="also replay the same graph on the TIMELINE build of the level's library (every wave "
                         "stamps the chip-wide 100 MHz clock; include/oc_hip.h: oc_timeline_begin) and report "
                         "roofline.kernel_active_us / boundary_us beside the unchanged headline")
+    p.add_argument("--settle-ms", type=float, default=SETTLE_MS,
+                   help="untimed graph replays before the calibration and the timed region")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -499,13 +503,15 @@ def main():
         blocks.prepare((args.warmup, SB))
         blocks.run(args.warmup)
         stream.synchronize()
-        # settle: on this box the first tens of milliseconds of GPU work after host-side idling
-        # (building the batch, capturing the graphs) can run ~10x slow (a clock / power ramp by its
-        # behaviour; tools/slow_replay_probe.py).  SETTLE_MS of untimed replays
-        # -- on top of the `--warmup` steps -- keep that transient out of the calibration and of
-        # the timed region.
+        # settle: a few untimed replays of the freshly instantiated graphs on top of the `--warmup`
+        # steps.  (Round 2 spent 150 ms here against a "slow stretch after host-side idling"; round 3
+        # found no slow GPU work behind it at all -- shader clock, kernel-active spans and launch
+        # boundaries are normal in every launch (tools/slow_stretch_probe.py); the replays of a "slow"
+        # run execute at the normal rate and start at once; what is late is the host's BLOCKED wait
+        # for the last event, by 50-80 ms (slow_stretch_probe4.py).  Event-timed medians never saw it;
+        # wall-clock loops did.  DESIGN.md section 7.)
         t_settle = time.perf_counter()
-        while (time.perf_counter() - t_settle) * 1e3 < SETTLE_MS:
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             blocks.run(SB)
             stream.synchronize()
 
@@ -537,6 +543,14 @@ def main():
         for r in range(replays):
             blocks.run(SB)                               # bpr blocks of EXACTLY K steps each
             evs[r + 1].record(stream)
+        # The host learns of the end of the region by POLLING the last event, not by a blocking wait:
+        # on this box a blocked hipEventSynchronize / hipDeviceSynchronize sometimes returns 50-80 ms
+        # after the device has finished (tools/slow_stretch_probe4.py: first event done at 0.4 ms, GPU
+        # span 5.4 ms, last event "done" on the host at 60-81 ms -- in 3 of 4 rounds that followed the
+        # building and dropping of eager batches; what round 2 took for a slow stretch of the GPU), and
+        # for N > 1 the wall clock over this region IS the value.
+        while not evs[-1].query():
+            pass
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -599,8 +613,16 @@ def main():
                 ent = tj.get(key, {})
                 traffic = ent.get("hbm_bytes_per_launch")
                 if traffic is not None:
-                    traffic_src = "%s (stored rocprofv3 --pmc passes: %s; not collected in this run)" % (
-                        "profiles/traffic.json", ent.get("source"))
+                    from gym_comm_amd import specialize
+                    now = specialize._source_digest().hexdigest()[:16]
+                    if ent.get("kernel_source_digest") != now:
+                        # counters of another kernel revision say nothing about this one
+                        traffic = None
+                        traffic_src = ("profiles/traffic.json holds counters of kernel source %s (%s); this is %s: "
+                                       "dropped" % (ent.get("kernel_source_digest"), ent.get("source"), now))
+                    else:
+                        traffic_src = "%s (stored rocprofv3 --pmc passes: %s, kernel source %s; not collected " \
+                                      "in this run)" % ("profiles/traffic.json", ent.get("source"), now)
             except Exception:
                 traffic = None
         kernel = "k_multi_step" if wrapper else "k_step"
@@ -628,9 +650,8 @@ def main():
                        "kernel_flavour": env.kernel_flavour,
                        **({"launches_per_step": (1 if loop.one_launch else 2) if args.policy == "fused" else "torch"}
                           if closed else {}),
-                       # (the general variant the closed loop launches splits four ways or not at all)
-                       "waves_per_64_envs": ((env.launch_waves_per_64 if not closed or env.launch_waves_per_64 == 4 else 1)
-                                             if wrapper else 1),
+                       # (what the library launches: the plain step open loop, the general variant closed loop)
+                       "waves_per_64_envs": env.launch_waves(general=closed) if wrapper else 1,
                        "parallelism": "env-sharded x%d" % world},
             "agent_steps_per_sec": value * lv.num_agents,
             "timing": {"what": "median over back-to-back blocks of `steps` steps (`reps` of them, "
@@ -638,9 +659,10 @@ def main():
                                "between replays, MAX over ranks",
                        "value_from": ("median block time (N = 1)" if world == 1 else
                                       "barrier-bracketed wall clock over the region, MAX over ranks (N > 1)"),
-                       "blocks_per_replay": bpr, "replays": replays, "settle_ms_untimed": SETTLE_MS,
+                       "blocks_per_replay": bpr, "replays": replays, "settle_ms_untimed": args.settle_ms,
                        "block_ms_min": block_s[0] * 1e3, "block_ms_median": med_block_s * 1e3,
-                       "block_ms_max": block_s[-1] * 1e3, "region_wall_s": wall},
+                       "block_ms_max": block_s[-1] * 1e3, "region_wall_s": wall,
+                       "region_gpu_span_s": evs[0].elapsed_time(evs[-1]) / 1e3},
             "rollout_metrics": {"env_steps": m[0], "episodes": m[1], "successes": m[2],
                                 "reward_sum": m[3], "completed_subtasks_sum": m[4], "errors": m[5]},
             "per_rank": [{"rank": r, "env_steps": pr[0], "episodes": pr[1], "successes": pr[2],

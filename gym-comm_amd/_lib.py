@@ -102,7 +102,7 @@ def _declare(L):
     L.oc_multi_step.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
                                 ctypes.c_int32, vp, vp, vp, ctypes.POINTER(StepOpts), ctypes.c_int64, vp]
     L.oc_random_actions.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
-    L.oc_multi_step_waves.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    L.oc_multi_step_waves.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
     L.oc_multi_step_waves.restype = ctypes.c_int32
     L.oc_timeline_begin.argtypes = [vp, ctypes.c_int64, ctypes.c_int64]
     for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_level_subtask_info",

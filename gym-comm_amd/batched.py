@@ -146,8 +146,15 @@ class BatchedOvercooked:
 
     @property
     def launch_waves_per_64(self):
-        """Waves per 64 envs the fused step is launched with (1, or 4 = split launch)."""
-        return int(self._L.oc_multi_step_waves(self.n, self.waves_per_64))
+        """Waves per 64 envs the PLAIN fused step is launched with (1, 2 or 4 = split launches)."""
+        return self.launch_waves(general=False)
+
+    def launch_waves(self, general=False):
+        """Waves per 64 envs the library launches for this batch (include/oc_hip.h:
+        oc_multi_step_waves): the plain step, or -- ``general`` -- the general variant (pairs /
+        in-kernel partner / episode statistics / policies / a non-standard wrapper configuration:
+        what ``OvercookedVecEnv`` launches), which splits four ways or not at all."""
+        return int(self._L.oc_multi_step_waves(self.n, self.waves_per_64, 1 if general else 0))
 
     # -- helpers ---------------------------------------------------------------
     def _on_device(self):

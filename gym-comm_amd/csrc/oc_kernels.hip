@@ -363,15 +363,24 @@ __device__ __forceinline__ int hide(int v) {
   asm("" : "+v"(v));
   return v;
 }
-__device__ __forceinline__ P p_eq(int a, int b) { return hide(a == b ? -1 : 0); }
-__device__ __forceinline__ P p_ne(int a, int b) { return hide(a != b ? -1 : 0); }
-__device__ __forceinline__ P p_gt_u(unsigned a, unsigned b) { return hide(a > b ? -1 : 0); }
-__device__ __forceinline__ P p_ge_u(unsigned a, unsigned b) { return hide(a >= b ? -1 : 0); }
-__device__ __forceinline__ P p_lt_u(unsigned a, unsigned b) { return hide(a < b ? -1 : 0); }
-__device__ __forceinline__ P p_gt_i(int a, int b) { return hide(a > b ? -1 : 0); }
-__device__ __forceinline__ P p_le_i(int a, int b) { return hide(a <= b ? -1 : 0); }
-__device__ __forceinline__ P p_nz(int a) { return hide(a != 0 ? -1 : 0); }
-__device__ __forceinline__ P p_z(int a) { return hide(a == 0 ? -1 : 0); }
+// How a P is born.  v_cmp + v_cndmask(0, -1) is two instructions, but every v_cmp writes vcc -- one
+// register for all of them, so the pairs cannot interleave -- and a v_cndmask reading it needs two
+// wait states behind the compare (the 3-agent kernel carried 80 s_nop).  For operands in
+// [0, 2^31) -- every field of the packed state -- the sign of a difference is the predicate:
+// two plain, independent VALU instructions (v_xad_u32 / v_sub + v_ashrrev_i32), no vcc, no nop.
+__device__ __forceinline__ P p_z(int a) { return hide((int)((unsigned)a - 1u) >> 31); }              // a == 0   (a >= 0)
+__device__ __forceinline__ P p_nz(int a) { return hide((int)(0u - (unsigned)a) >> 31); }             // a != 0   (a >= 0)
+__device__ __forceinline__ P p_eq(int a, int b) { return hide((int)((unsigned)(a ^ b) - 1u) >> 31); }  // (bit 31 of a, b equal)
+__device__ __forceinline__ P p_ne(int a, int b) { return ~p_eq(a, b); }
+__device__ __forceinline__ P p_lt(int a, int b) { return hide((a - b) >> 31); }                      // a < b    (0 <= a, b < 2^31)
+__device__ __forceinline__ P p_gt(int a, int b) { return p_lt(b, a); }
+__device__ __forceinline__ P p_ge(int a, int b) { return ~p_lt(a, b); }
+__device__ __forceinline__ P p_le(int a, int b) { return ~p_lt(b, a); }
+// ... and for operands of any value (caller-supplied action indices, 32-bit subtask masks): the compare
+__device__ __forceinline__ P p_eq_any(int a, int b) { return hide(a == b ? -1 : 0); }
+__device__ __forceinline__ P p_gtu_any(unsigned a, unsigned b) { return hide(a > b ? -1 : 0); }
+__device__ __forceinline__ P p_geu_any(unsigned a, unsigned b) { return hide(a >= b ? -1 : 0); }
+__device__ __forceinline__ P p_ltu_any(unsigned a, unsigned b) { return hide(a < b ? -1 : 0); }
 __device__ __forceinline__ P p_bit(int w, unsigned k) { return __builtin_amdgcn_sbfe(w, k, 1u); }  // bit k as 0 / -1: one v_bfe_i32
 __device__ __forceinline__ P p_of(bool uniform) { return uniform ? -1 : 0; }                       // a wave-uniform condition
 __device__ __forceinline__ int sel(P m, int a, int b) { return (a & m) | (b & ~m); }               // v_bfi_b32
@@ -390,7 +399,8 @@ __device__ __forceinline__ int manhattan(int p, int q) {   // packed cells x | y
 __device__ __forceinline__ int px(int p) { return p & 15; }
 __device__ __forceinline__ int py(int p) { return p >> 4; }
 __device__ __forceinline__ int dense(const Hdr &L, int p) {
-  return (int)(__umul24((unsigned)py(p), (unsigned)L.W()) + (unsigned)px(p));  // v_mad_u32_u24
+  // y * W + x from p = x + 16 y without unpacking x: p - (16 - W) * y  (v_lshrrev + v_mad_i32_i24)
+  return __mul24(py(p), L.W() - 16) + p;
 }
 // bit c of a 128-bit plane held as two 64-bit words
 __device__ __forceinline__ int bit128(uint64_t w0, uint64_t w1, int c) {
@@ -454,7 +464,7 @@ __device__ __forceinline__ double timestep_of(int t, const RunCfg &R) {
 // through one.  Since v11 no wave waits for its stores, and round 2 re-measured
 // (tools/wt_threshold.sh): write-through is never slower, 3.64 -> 3.51 us at n = 4096, 3.53 ->
 // 3.46 us at 512, 3.44 -> 3.43 us at 64, salad-2 x 4096 3.89 -> 3.74 us.  The launcher picks the
-// write-through variant (template bool WT) at every batch size; OC_WRITE_THROUGH=0 restores
+// write-through variant (template bool WT) at every batch size; OC_LAUNCH=wt=0 restores
 // write-back stores.
 template <int AUX>
 struct RowsT {
@@ -818,7 +828,7 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
 #pragma unroll
   for (int a = 0; a < A; a++) {
     int c = act_in[a];
-    e.err |= p_gt_u((unsigned)c, 4u) & OC_ERR_ACTION;   // no such NAV action: flagged, executed as (0, 0)
+    e.err |= p_gtu_any((unsigned)c, 4u) & OC_ERR_ACTION;   // no such NAV action: flagged, executed as (0, 0)
     c = (int)min((unsigned)c, 4u);
     act[a] = c;
     moving[a] = p_ne(c, OC_ACT_NOOP);
@@ -834,7 +844,7 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
       const int dx = (c == OC_ACT_RIGHT) - (c == OC_ACT_LEFT);
       const int dy = (c == OC_ACT_DOWN) - (c == OC_ACT_UP);
       const int qx = px(e.ap[a]) + dx, qy = py(e.ap[a]) + dy;
-      oob = ~(p_lt_u((unsigned)qx, (unsigned)W) & p_lt_u((unsigned)qy, (unsigned)H));
+      oob = ~(p_ltu_any((unsigned)qx, (unsigned)W) & p_ltu_any((unsigned)qy, (unsigned)H));
       e.err |= oob & OC_ERR_OOB;  // get_gridsquare_at asserts (utils/world.py:310-315)
       const int tx = min(max(qx, 0), W - 1), ty = min(max(qy, 0), H - 1);  // world.inbounds (world.py:317-320)
       tgt_p[a] = tx | (ty << 4);
@@ -855,6 +865,7 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
     np[a] = sel(t_nonfloor[a] | oob, e.ap[a], tgt_p[a]);  // :551-559
   }
   P ex[A];
+  P may_share = 0;   // (A > 2) two agents may come to stand on one cell during this step: see the alias check below
 #pragma unroll
   for (int a = 0; a < A; a++) ex[a] = -1;
 #pragma unroll
@@ -864,12 +875,18 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
       const P same = p_eq(np[i], np[j]);  // :562-569
       const P i_stays = p_eq(np[i], e.ap[i]) & moving[i];
       const P j_stays = p_eq(np[j], e.ap[j]) & moving[j];
-      const P swap = p_eq(e.ap[i], np[j]) & p_eq(e.ap[j], np[i]);  // :572-575
+      const P i_on_j = p_eq(e.ap[i], np[j]), j_on_i = p_eq(e.ap[j], np[i]);
+      const P swap = i_on_j & j_on_i;  // :572-575
       const P block_i = sel(same, ~i_stays, swap);
       const P block_j = sel(same, i_stays | ~j_stays, swap);
       ex[i] &= ~block_i;
       ex[j] &= ~block_j;
+      if (A > 2) may_share |= same | i_on_j | j_on_i | p_eq(e.ap[i], e.ap[j]);
     }
+  // ONE wave ballot per step (a scalar read of a vector-written mask: ~16 cycles, see `hide`) decides
+  // whether any agent's interact() has to look for the World.remove alias corner at all: it needs
+  // two agents on one cell, and an agent is only ever on its old or its proposed cell
+  const bool wave_may_share = A > 2 && __ballot(may_share != 0) != 0;
 
   // ---- execute_navigation (:615-618): interact(), sequential in agent order ---
   // decision phase + one bit-field insert per item (utils/interact.py:4-75)
@@ -893,7 +910,8 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
     for (int i = 0; i < M; i++) {
       const int w = e.iw[i];
       const int u = item_type(L, i) != OC_PLATE ? (w ^ IW_CHOP) : w;  // uniform choice; a Plate is never chopped
-      mine[i] = p_eq(w & IW_HOLD, hold_code);
+      // (two agents: holder + 1 is 0, 1 or 2, so "held by agent a" is ONE bit of the word)
+      mine[i] = A == 2 ? p_bit(w, 12 + a) : p_eq(w & IW_HOLD, hold_code);
       tgt[i] = p_eq(w & (IW_HOLD | IW_POS), tp);                       // unheld and on the target cell
       held_or |= mine[i] & u;
       tgt_or |= tgt[i] & u;
@@ -904,7 +922,7 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
       int nm = 0;
 #pragma unroll
       for (int i = 0; i < M; i++) nm -= mine[i];
-      held_multi = p_gt_i(nm, 1);
+      held_multi = p_gt(nm, 1);
     } else {
       held_multi = p_nz(held_or & IW_TSET & ((held_or & IW_TSET) - (1 << 24)));
     }
@@ -956,19 +974,18 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
       // Object that sits later in world order it removes the wrong one and the
       // reference's store is corrupt from here on.  Flag it.
       // Only reachable when another agent stands on this agent's cell (the 3-agent overlap
-      // quirk of check_collisions) while this one merges: one ballot skips the item scan for
-      // the whole wave in every other step.
-      P shared = 0;
+      // quirk of check_collisions) while this one merges.
+      if (wave_may_share) {   // uniform, decided before the first interact()
+        P shared = 0;
 #pragma unroll
-      for (int b = 0; b < A; b++)
-        if (b != a) shared |= p_eq(e.ap[b], pa);
-      if (__ballot((shared & do_merge) != 0) != 0) {
+        for (int b = 0; b < A; b++)
+          if (b != a) shared |= p_eq(e.ap[b], pa);
         P alias = 0;
 #pragma unroll
         for (int j = 0; j < M; j++) {
           const int w = e.iw[j];
           alias |= p_nz(w & IW_HOLD) & p_ne(w & IW_HOLD, hold_code) & p_eq(ipos(w), pa) &
-                   p_z((w ^ held_or) & TS<DUP>) & p_gt_i(w & IW_SEQ, held_or & IW_SEQ);
+                   p_z((w ^ held_or) & TS<DUP>) & p_gt(w & IW_SEQ, held_or & IW_SEQ);
         }
         e.err |= shared & do_merge & alias & OC_ERR_ALIAS;
       }
@@ -1062,7 +1079,7 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
         }
         cnt = min(cnt, 3);
         const int old = (e.goalcnt >> (2 * g)) & 3;
-        rose |= p_gt_i(cnt, old) & (int)L.goal_nd(g);
+        rose |= p_gt(cnt, old) & (int)L.goal_nd(g);
         cnt_mask |= cnt << (2 * g);
         del_mask |= hasd & (int)L.goal_dl(g);
       }
@@ -1080,8 +1097,8 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
   reward = __popc(newly) + 3 * __popc(del_mask);  // Deliver pays +3 every step (:400-406)
   e.completed |= newly | del_mask;
   e.goalcnt = cnt_mask;
-  const P timeout = R.T != 0 ? p_ge_u((unsigned)e.t, (unsigned)R.T) : 0;  // checked first (:245-249)
-  const P all_delivered = p_eq(del_mask, (int)L.deliver_mask());
+  const P timeout = R.T != 0 ? p_ge(e.t, R.T) : 0;  // checked first (:245-249)
+  const P all_delivered = p_eq_any(del_mask, (int)L.deliver_mask());   // (32-bit subtask masks)
   done = (timeout | all_delivered) & 1;
   success = (~timeout & all_delivered) & 1;
 
@@ -1877,7 +1894,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     const unsigned NC = (unsigned)p.cfg.obs.num_comm;
     // (per-lane predicates are P words, 0 / -1, see `hide`; the cfg_* tests are wave-uniform)
     const bool ego_talks = cfg_comm_on, alt_talks = cfg_comm_on && !cfg_ego_led;
-    const P ego_cm_bad = p_ge_u((unsigned)ego_cm, NC), alt_cm_bad = p_ge_u((unsigned)alt_cm, NC);
+    const P ego_cm_bad = p_geu_any((unsigned)ego_cm, NC), alt_cm_bad = p_geu_any((unsigned)alt_cm, NC);
     const P bad_cm = (p_of(ego_talks) & ego_cm_bad) | (p_of(alt_talks) & alt_cm_bad);
     const int c0 = ego_talks ? (ego_cm | ego_cm_bad) : -1;    // the index, or -1 = nothing sent
     const int c1 = alt_talks ? (alt_cm | alt_cm_bad) : -1;
@@ -1887,7 +1904,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     }
     // NAV_ACTIONS lookup (both indices, moved or not: :248) + CAN_MOVE gating + ego_agent_idx
     // (:250-262); NAV_ACTIONS[idx] raises for idx > 3: flagged, executed as (0, 0)
-    const P bad_mv = p_gt_u((unsigned)ego_mv, 3u) | p_gt_u((unsigned)alt_mv, 3u);
+    const P bad_mv = p_gtu_any((unsigned)ego_mv, 3u) | p_gtu_any((unsigned)alt_mv, 3u);
     const int em = (cfg_can_move & 1) ? (int)min((unsigned)ego_mv, 4u) : OC_ACT_NOOP;   // (> 3 -> 4 = OC_ACT_NOOP)
     const int am = (cfg_can_move & 2) ? (int)min((unsigned)alt_mv, 4u) : OC_ACT_NOOP;
     int act[A];
@@ -2103,13 +2120,53 @@ unsigned long long *timeline_next(int64_t waves, int64_t &stride) {
   return nullptr;
 }
 
+// ---- launch policy ---------------------------------------------------------------------------
+// ONE knob for measurements and tests forces what the library otherwise decides per call:
+//   OC_LAUNCH="split=4,step_split=1,wt=0,lds=1,block=128"      (any subset, comma separated)
+//     split       waves per 64 envs of the fused step (oc_multi_step): 1, 2 or 4     [split_for]
+//     step_split  waves per 64 envs of the base step (oc_step): 1 or 2                [step_split_for]
+//     wt          1 = write-through (sc1) stores, 0 = write-back                      [write_through]
+//     lds         1 = the lane-indexed tables staged in LDS (one wave per 64 envs)    [tables_in_lds]
+//     block       threads per workgroup of an unsplit launch: 64, 128 or 256          [block_size_for]
+// Read at EVERY call (a getenv and a string compare), so one process can run several policies --
+// tests/test_hip_parity.py::test_forced_launch_policies does.  Results never depend on it.
+// (Round 2 had six variables, three of them latched at first use; they are gone.)
+struct LaunchPolicy {
+  int split = 0, step_split = 0, wt = -1, lds = -1, block = 0;
+};
+LaunchPolicy launch_policy() {
+  static thread_local char seen[128] = "\x01";
+  static thread_local LaunchPolicy cur;
+  const char *v = getenv("OC_LAUNCH");
+  if (!v) v = "";
+  if (strncmp(v, seen, sizeof(seen)) == 0) return cur;
+  snprintf(seen, sizeof(seen), "%s", v);
+  LaunchPolicy p;
+  for (const char *q = v; *q;) {
+    int val = 0;
+    char key[16] = "";
+    int used = 0;
+    if (sscanf(q, " %15[a-z_]=%d%n", key, &val, &used) == 2) {
+      if (!strcmp(key, "split") && (val == 1 || val == 2 || val == 4)) p.split = val;
+      else if (!strcmp(key, "step_split") && (val == 1 || val == 2)) p.step_split = val;
+      else if (!strcmp(key, "wt") && (val == 0 || val == 1)) p.wt = val;
+      else if (!strcmp(key, "lds") && (val == 0 || val == 1)) p.lds = val;
+      else if (!strcmp(key, "block") && (val == 64 || val == 128 || val == 256)) p.block = val;
+      q += used;
+    }
+    while (*q && *q != ',') q++;
+    if (*q == ',') q++;
+  }
+  cur = p;
+  return cur;
+}
+
 int block_size_for(int64_t) {
   // One wave per workgroup spreads a batch over the most CUs and measured fastest at every
   // batch size from 4 096 to 524 288 envs (MI355X sweeps, profiles/r01_v3_block_lds_sweep.txt,
-  // r01_v11_geometry_sweep.txt).  OC_BLOCK overrides (tuning / tests).
-  static const int forced = getenv("OC_BLOCK") ? atoi(getenv("OC_BLOCK")) : 0;
-  if (forced == 64 || forced == 128 || forced == 256) return forced;
-  return 64;
+  // r01_v11_geometry_sweep.txt).
+  const int forced = launch_policy().block;
+  return forced ? forced : 64;
 }
 
 // rows are addressed with 32-bit byte offsets through a buffer descriptor
@@ -2172,47 +2229,42 @@ int launch_ms_split(K kernel, int sp, const MultiArgs &a, int64_t n, void *strea
   return OC_OK;
 }
 
-// Waves per 64 envs for the fused step (see multi_step_body).  Four while every wave still gets a
-// SIMD of its own -- 4 * n / 64 <= 1 024 SIMDs (256 CUs x 4), i.e. n <= 16 384 on an MI355X -- and a
-// little beyond (up to 24 576 envs: 1.5 waves per SIMD); two (state + viewer 0 | shaping +
-// viewer 1: one wave per SIMD again) up to 32 768; one beyond.
-// tools/split_sweep.sh, us per step, one / two / four waves per 64 envs:
-//   tomato-2  n = 64 3.26 / - / 2.97, 4 096 3.55 / 3.26 / 3.07, 16 384 3.83 / 3.42 / 3.24,
-//             24 576 3.98 / 3.86 / 3.67, 28 672 4.03 / 3.94 / 3.79, 32 768 4.05 / 4.11 / 3.93,
-//             49 152 4.34 / 4.57 / 4.62, 65 536 5.35 / 5.51 / 5.44, 131 072 7.99 / 8.18 / 12.3
-//   salad-2   24 576 4.26 / 3.89 / 4.00, 28 672 4.30 / 4.00 / 4.14, 32 768 4.34 / 4.15 / 4.46,
-//             49 152 4.80 / 4.88 / 4.95;   tl-2  28 672 4.32 / 3.89 / 3.77, 32 768 4.34 / 4.09 / 4.17
-// (between 24 576 and 32 768 envs two waves win on three of the four levels measured and lose
-// 1.7 % on the fourth.)
-// The caller's hint (oc_step_opts.waves_per_64 = 1 / 2 / 4) and OC_SPLIT=1/2/4 (tuning) override.
+// Waves per 64 envs for the fused step (see multi_step_body): four up to 32 768 envs, one beyond.
+// us per step, one / two / four waves per 64 envs (tools/ab_set.sh, MI355X, round-3 kernels --
+// predicates as VALU words, ~4 cycles per instruction):
+//   tomato-2  4 096 3.41 / - / 2.82   16 384 - / - / 2.95   32 768 - / 4.13 / 3.75   40 960 3.93 / - / 4.40
+//             49 152 4.14 / - / 4.48   65 536 4.94 / 5.17 / 5.31   131 072 7.73 / - / -
+//   salad-2   32 768 4.08 / 4.32 / 3.97
+// (Round 2, at ~7 cycles per instruction: four up to 24 576, two up to 32 768 -- the two-way split
+// no longer wins anywhere and is only launched on the caller's hint.)
+// The caller's hint (oc_step_opts.waves_per_64 = 1 / 2 / 4) and OC_LAUNCH=split=... override.
 int split_for(int64_t n, int hint) {
-  static const int forced = getenv("OC_SPLIT") ? atoi(getenv("OC_SPLIT")) : 0;
-  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  const int forced = launch_policy().split;
+  if (forced) return forced;
   if (hint == 1 || hint == 2 || hint == 4) return hint;
-  return n <= 24576 ? 4 : n <= 32768 ? 2 : 1;
+  return n <= 32768 ? 4 : 1;
 }
 
-// The same for the base step (k_step<..., SP = 2>: state wave + shaping wave).  OC_STEP_SPLIT=1/2
-// overrides; read at every call, so that tests can run both launches in one process.
+// The same for the base step (k_step<..., SP = 2>: state wave + shaping wave): two up to 16 384
+// envs (tl-3: 16 384 3.44 -> 3.00 us, 24 576 3.51 / 3.97, 32 768 3.58 / 4.06, 65 536 3.82 / 4.38).
 int step_split_for(int64_t n) {
-  const char *f = getenv("OC_STEP_SPLIT");
-  if (f && (f[0] == '1' || f[0] == '2') && !f[1]) return f[0] - '0';
+  const int forced = launch_policy().step_split;
+  if (forced) return forced;
   return n <= 16384 ? 2 : 1;
 }
 
 bool write_through(int64_t n) {
-  // sc1 stores (see RowsT) at every batch size (tools/wt_threshold.sh); OC_WRITE_THROUGH=0/1 overrides (tuning / tests)
-  static const int forced = getenv("OC_WRITE_THROUGH") ? atoi(getenv("OC_WRITE_THROUGH")) : -1;
+  // sc1 stores (see RowsT) at every batch size (tools/wt_threshold.sh)
   (void)n;
+  const int forced = launch_policy().wt;
   return forced >= 0 ? forced == 1 : true;
 }
 
 bool tables_in_lds(int64_t) {
   // Off by default: with one- or two-wave workgroups the staging pass + barrier never paid
   // in the sweep (it only wins with 256-thread workgroups, which lose overall).
-  // OC_TABLES_LDS=1 selects the LDS variant (kept compiled, tested, and measured).
-  static const int forced = getenv("OC_TABLES_LDS") ? atoi(getenv("OC_TABLES_LDS")) : -1;
-  return forced == 1;
+  // OC_LAUNCH=lds=1 selects the LDS variant (kept compiled, tested, and measured).
+  return launch_policy().lds == 1;
 }
 
 // X(A, M, DUP): one instantiation per (agents, items, dup mode).  `A_`, `M_`, `D_` are locals of
@@ -2808,8 +2860,7 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   const bool std_cfg = cfg->communication_on && !cfg->ego_led && cfg->can_move_mask == 3 &&
                        cfg->ego_agent_idx == 0 && cfg->obs.blind_mask == 0 && !lv->run.play;
   const bool xo = o.ep_return || o.ego_pairs || o.alt_pairs || o.alt_rng || !std_cfg;
-  const int sp = oc_multi_step_waves(n, o.waves_per_64);
-  (void)sp;   // split launch: write-through stores, tables in global memory
+  const int sp = oc_multi_step_waves(n, o.waves_per_64, xo ? 1 : 0);   // (the launch actually taken, see there)
 #define OC_MS_X(MM, DD, XX)                                                           \
   do {                                                                                \
     if (in_lds && ot == 0) return launch_ms(k_multi_step<MM, true, 0, false, DD, XX, 1>, a, n, stream, lds);  \
@@ -2900,8 +2951,15 @@ int oc_timeline_begin(uint64_t *records, int64_t count, int64_t stride) {
 #endif
 }
 
-int32_t oc_multi_step_waves(int64_t n, int32_t hint) {
-  return (write_through(n) && !tables_in_lds(n)) ? split_for(n, hint) : 1;
+int32_t oc_multi_step_waves(int64_t n, int32_t hint, int32_t general_variant) {
+  // the policy's wish ...
+  const int sp = (write_through(n) && !tables_in_lds(n)) ? split_for(n, hint) : 1;
+  // ... and what this library has kernels for (the same predicate oc_multi_step dispatches on):
+#ifdef OC_SPECIALIZED
+  return general_variant ? (sp == 4 ? 4 : 1) : sp;   // the general variant splits four ways or not at all
+#else
+  return (!general_variant && sp == 4) ? 4 : 1;      // the generic library splits the plain variant four ways only
+#endif
 }
 
 int oc_random_actions(uint32_t *rng, int32_t *move_row, int32_t *comm_row, int32_t num_comm, int64_t n,

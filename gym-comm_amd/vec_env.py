@@ -400,8 +400,15 @@ class FusedMLPPartner:
     share one launch (``FusedMLPPartner.launch``).  Weights are packed once (``refresh()`` after an
     optimiser step); fp16 operands, fp32 accumulation: logits within 2e-2 of the fp32 module's."""
     graph_safe = True
+    _seats = 0          # partners built so far: the default stream seed differs from seat to seat
 
-    def __init__(self, policy, sample=True, seed=0, device="cuda", keep_logits=False):
+    def __init__(self, policy, sample=True, seed=None, device="cuda", keep_logits=False):
+        # seed=None: a different default per partner built (two seats left at their defaults -- an
+        # ego and a partner -- must not share per-env random streams: their samples would use the
+        # same uniform draw every step, ADVICE r2); pass a seed for a reproducible stream
+        if seed is None:
+            seed = 0x5EED + 1000003 * FusedMLPPartner._seats
+        FusedMLPPartner._seats += 1
         if not isinstance(policy, MLPPolicy):
             raise TypeError("FusedMLPPartner runs gym_comm_amd.vec_env.MLPPolicy; wrap any other module "
                             "in TorchPolicyPartner")
@@ -544,7 +551,7 @@ class ClosedLoop:
                and pt.C == ego.C and ego.C <= 4 and venv._b.kernel_flavour == "spec")
         if one_launch and not can:
             raise ValueError("one_launch needs two FusedMLPPartner of one shape, C <= 4 and a specialised library")
-        self.one_launch = (can and venv._b.launch_waves_per_64 == 4) if one_launch is None else bool(one_launch)
+        self.one_launch = (can and venv._b.launch_waves(general=True) == 4) if one_launch is None else bool(one_launch)
         self._primed = False
         self.prime()
         venv._loops.add(self)       # reset_tensors() re-primes every live loop (weak references)

@@ -110,8 +110,8 @@ typedef struct {
  *            1 = one wave computes the whole step of its 64 envs, 4 = "split launch": four waves
  *            per 64 envs (one workgroup = the four SIMDs of a CU), each producing one of the
  *            step's outputs -- state + metrics / shaped reward / viewer 0 / viewer 1; 2 = two
- *            waves (state + viewer 0 / shaping + viewer 1).  The library picks 4 up to 24 576
- *            envs (3.55 -> 3.07 us per step at 4 096 envs on an MI355X), 2 up to 32 768, 1 beyond.
+ *            waves (state + viewer 0 / shaping + viewer 1).  The library picks 4 up to 32 768
+ *            envs (3.41 -> 2.82 us per step at 4 096 envs on an MI355X), 1 beyond.
  *            Any other value = 0.
  *   policy   NULL, or oc_step_policy[2] (HOST array, read at the call): the closed loop in ONE
  *            launch.  After the step, the kernel itself evaluates both players' MLP policies
@@ -255,10 +255,14 @@ OC_API int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, co
                   const int32_t *placement, uint32_t *rng, const oc_step_opts *opts,
                   int64_t n, void *stream);
 
-/* Waves per 64 envs oc_multi_step will launch for a batch of n envs given the caller's hint
- * (oc_step_opts.waves_per_64): 1, 2 or 4 (the plain variant; the general one splits four ways or
- * not at all).  Host only; for reports and tests. */
-OC_API int32_t oc_multi_step_waves(int64_t n, int32_t hint);
+/* Waves per 64 envs oc_multi_step WILL LAUNCH for a batch of n envs given the caller's hint
+ * (oc_step_opts.waves_per_64) and the variant the call selects -- general_variant != 0: any of
+ * oc_step_opts' action sources / episode statistics / policy, or a non-standard wrapper
+ * configuration; 0: the plain step.  1, 2 or 4: the general variant splits four ways or not at
+ * all, the generic (unspecialised) library splits the plain variant four ways only; OC_LAUNCH
+ * (a measurement knob, csrc/oc_kernels.hip: launch_policy) overrides the policy, never the
+ * results.  Host only; for reports and tests. */
+OC_API int32_t oc_multi_step_waves(int64_t n, int32_t hint, int32_t general_variant);
 
 /* Measurement hook of the TIMELINE build flavour (the same source compiled with -DOC_TIMELINE=1;
  * gym-comm_amd/specialize.py, variant="timeline"; every other build returns OC_E_BADARG).  In such a

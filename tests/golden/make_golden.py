@@ -395,6 +395,9 @@ DUP_LEVELS = {
     "custom-two_tomatoes": "-t---t-\n/     l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSimpleTomato\n\n2 1\n4 1\n4 4\n2 4",
     "custom-two_lettuces_salad": "-l---t-\n/     l\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSalad\n\n2 1\n4 1\n4 4\n2 4",
     "custom-two_tomatoes_small": "-t/t-\n-   p\n*   p\n-----\n\nSimpleTomato\n\n1 1\n3 2\n2 1",
+    # THREE of a type (round 3): the count == 3 paths -- the 2-bit goal counts at their
+    # maximum, three candidates in the set-order lookup, five items
+    "custom-three_tomatoes": "-t-t-t-\n/     -\n/     -\n*     -\n-     -\n-     p\n-----p-\n\nSimpleTomato\n\n2 1\n4 1\n4 4\n2 4",
 }
 
 
@@ -420,9 +423,11 @@ def main_play(summary):
         print(fn, summary[fn], flush=True)
 
 
-def main_dup(summary):
+def main_dup(summary, only3=False):
     H.use_custom_levels(DUP_LEVELS)
-    jobs = [("custom-two_tomatoes", 2, 200, [("purpose", (7000, 80))]),
+    jobs = [("custom-three_tomatoes", 2, 200, [("purpose", (9000, 86))]),
+            ("custom-three_tomatoes", 3, 150, [("purpose", (5000, 87))])]
+    jobs += [] if only3 else [("custom-two_tomatoes", 2, 200, [("purpose", (7000, 80))]),
             ("custom-two_tomatoes", 3, 150, [("purpose", (4000, 81))]),
             ("custom-two_lettuces_salad", 2, 250, [("purpose", (9000, 82))]),
             ("custom-two_tomatoes_small", 2, 120, [("rand5", (1500, 83)), ("purpose", (6000, 84))]),
@@ -438,10 +443,11 @@ def main_dup(summary):
                        "steps_with_goal_count_above_1": int((out["goal_count"] > 1).any(axis=1).sum()),
                        "max_objects": int(out["nobj"].max()), "min_objects": int(out["nobj"].min())}
         print(fn, summary[fn], "S=%d" % len(st["subtasks"]), flush=True)
-    for name, level, T, steps, seed, kw in [
+    wrap_jobs = [("dup_three_tomatoes_r2", "custom-three_tomatoes", 200, 7000, 143, {})]
+    for name, level, T, steps, seed, kw in wrap_jobs + ([] if only3 else [
             ("dup_two_tomatoes_r2", "custom-two_tomatoes", 200, 6000, 140, {}),
             ("dup_two_lettuces_salad_c3", "custom-two_lettuces_salad", 250, 8000, 141, {"num_communication": 3, "fow_radius": 1}),
-            ("dup_two_tomatoes_small_r1", "custom-two_tomatoes_small", 120, 5000, 142, {"fow_radius": 1})]:
+            ("dup_two_tomatoes_small_r1", "custom-two_tomatoes_small", 120, 5000, 142, {"fow_radius": 1})]):
         out, nd = run_wrapper(name, level, T, steps, seed, **kw)
         st = json.loads(str(out["static_json"]))
         st["level_text"] = DUP_LEVELS[level]
@@ -529,10 +535,10 @@ def main():
         with open(os.path.join(HERE, "SUMMARY.json"), "w") as f:
             json.dump(summary, f, indent=1, sort_keys=True)
         return
-    if "--dup-only" in sys.argv:
+    if "--dup-only" in sys.argv or "--dup3-only" in sys.argv:
         with open(os.path.join(HERE, "SUMMARY.json")) as f:
             summary = json.load(f)
-        main_dup(summary)
+        main_dup(summary, only3="--dup3-only" in sys.argv)
         with open(os.path.join(HERE, "SUMMARY.json"), "w") as f:
             json.dump(summary, f, indent=1, sort_keys=True)
         return

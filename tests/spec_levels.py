@@ -21,13 +21,16 @@ SPEC_GOLDEN = ["base_open-divider_tomato_a2.npz", "base_full-divider_salad_a2.np
                "cbase_dup_two_tomatoes_a2.npz", "cbase_dup_two_tomatoes_small_a3.npz",
                "cbase_dup_two_lettuces_salad_a2.npz", "cwrap_dup_two_lettuces_salad_c3.npz",
                "cwrap_dup_two_tomatoes_small_r1.npz",
+               # ... three times (the count == 3 paths: 2-bit goal counts at their maximum, five items)
+               "cbase_dup_three_tomatoes_a2.npz", "cbase_dup_three_tomatoes_a3.npz", "cwrap_dup_three_tomatoes_r2.npz",
                # arglist.play = True (a run-time flag: the same libraries)
                "pbase_open-divider_tomato_a2.npz", "pbase_partial-divider_tl_a3.npz", "pwrap_play_salad_c3.npz"]
 
 
 # fixtures whose level (canonical subtask order) the seeded dup-mode test steps
 DUP_SEEDED = [("cbase_dup_two_tomatoes_small_a2.npz", 2), ("cbase_dup_two_tomatoes_small_a3.npz", 3),
-              ("cbase_dup_two_lettuces_salad_a2.npz", 2), ("cbase_dup_two_tomatoes_a3.npz", 3)]
+              ("cbase_dup_two_lettuces_salad_a2.npz", 2), ("cbase_dup_two_tomatoes_a3.npz", 3),
+              ("cbase_dup_three_tomatoes_a2.npz", 2), ("cbase_dup_three_tomatoes_a3.npz", 3)]
 
 
 def all_spec_levels():

@@ -160,13 +160,14 @@ print("LDS-variant ok")
 
 
 def test_lds_table_variant_in_subprocess():
-    """The LDS-staged-table kernel variant (OC_TABLES_LDS=1, 256-thread workgroups) is not
-    the default; it is selected per process, so check it in a child process."""
+    """The LDS-staged-table kernel variant (OC_LAUNCH=lds=1, 256-thread workgroups) is not
+    the default; checked in a child process at BASELINE sizes (a short in-process compare of
+    every forced policy: test_hip_parity.py::test_forced_launch_policies)."""
     import os
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, OC_TABLES_LDS="1", OC_BLOCK="256")
+    env = dict(os.environ, OC_LAUNCH="lds=1,block=256")
     out = subprocess.run([sys.executable, "-c", _LDS_SNIPPET % (ROOT, os.path.join(ROOT, "tests"))],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "LDS-variant ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
@@ -206,7 +207,7 @@ print("store-policy variant ok")
 @pytest.mark.parametrize("wt", ["0", "1"])
 def test_store_policy_variants_in_subprocess(wt):
     """The launcher picks default-policy stores below 8192 envs and write-through (sc1)
-    stores from there on; OC_WRITE_THROUGH forces one of them per process.  Both variants
+    stores from there on; OC_LAUNCH=wt=0/1 forces one of them.  Both variants
     of the fused kernel (int32 and int8 observation rows) against the oracle at a size where
     the forced variant is NOT the default one (wt=1 at n=1111); wt=0 doubles as the check
     that the override is harmless."""
@@ -214,7 +215,7 @@ def test_store_policy_variants_in_subprocess(wt):
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, OC_WRITE_THROUGH=wt)
+    env = dict(os.environ, OC_LAUNCH="wt=" + wt)
     out = subprocess.run([sys.executable, "-c", _WT_SNIPPET % (ROOT, os.path.join(ROOT, "tests"))],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "store-policy variant ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -158,7 +158,7 @@ def test_step_matches_oracle_seeded(level, A, T, spec, waves, oracle_lib, monkey
     specialised libraries launch the step split over two waves per 64 envs (state wave + shaping
     wave) at this batch size; `1wave` forces the one-wave launch large batches get."""
     from gym_comm_amd import compiler
-    monkeypatch.setenv("OC_STEP_SPLIT", str(waves))
+    monkeypatch.setenv("OC_LAUNCH", "step_split=%d" % waves)
     lv = compiler.compile_level(level, A, T)
     n, steps = 1000, 260
     rng = np.random.default_rng(1234 + A)
@@ -570,7 +570,10 @@ def test_error_flags_match_oracle(oracle_lib):
 
 
 DUP_SEEDED = [("cbase_dup_two_tomatoes_small_a2.npz", 2), ("cbase_dup_two_tomatoes_small_a3.npz", 3),
-              ("cbase_dup_two_lettuces_salad_a2.npz", 2), ("cbase_dup_two_tomatoes_a3.npz", 3)]
+              ("cbase_dup_two_lettuces_salad_a2.npz", 2), ("cbase_dup_two_tomatoes_a3.npz", 3),
+              # three of a type: goal counts reach 3 -- the 2-bit field's maximum -- in 29
+              # env-steps of the 3-agent run (and in 44 steps of the a2 FIXTURE, replayed above)
+              ("cbase_dup_three_tomatoes_a2.npz", 2), ("cbase_dup_three_tomatoes_a3.npz", 3)]
 
 
 @pytest.mark.parametrize("spec", [False, True], ids=["generic", "spec"])
@@ -592,7 +595,7 @@ def test_dup_levels_match_oracle_seeded(name, A, spec, oracle_lib):
     env = _env(lv, n, auto_reset=True, specialize_level=spec)
     assert env.kernel_flavour == ("spec" if spec else "generic") and env.W_state == A + lv.num_items + 4
     acts_d = torch.from_numpy(acts).cuda()
-    tot_r = above1 = merges = flagged = 0
+    tot_r = above1 = merges = flagged = at3 = 0
     was = np.zeros(n, bool)
     for k in range(steps):
         r, d, sh = env.step(acts_d[k])
@@ -612,8 +615,10 @@ def test_dup_levels_match_oracle_seeded(name, A, spec, oracle_lib):
         assert_snapshots_equal(hs, os_, ctx, where=clean)
         tot_r += int(ro.sum())
         above1 += int((os_["goal_count"] > 1).any(axis=1).sum())
+        at3 += int((os_["goal_count"] >= 3).any(axis=1).sum())
         merges += int((os_["nobj"] < lv.num_items).sum())
     assert tot_r > 0 and above1 > 0 and merges > 0, (tot_r, above1, merges)
+    assert at3 == {"cbase_dup_three_tomatoes_a3.npz": 29}.get(name, 0), at3
     # exact flagged fraction (counted with the oracle on the CPU): env-steps spent flagged, of 390 000
     assert flagged == {"cbase_dup_two_tomatoes_small_a3.npz": 72}.get(name, 0), flagged
     if A == 2:
@@ -784,3 +789,51 @@ def test_custom_map_runs_on_the_library_of_its_structure(oracle_lib):
         oo, to, ro, do = ora.multi_step(a, comm, 1, 0, C, auto_reset=True)
         assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(bits(r.cpu().numpy()), bits(ro)), k
         assert np.array_equal(bits(t.cpu().numpy()), bits(to)) and np.array_equal(d.cpu().numpy(), do), k
+
+
+FORCED = ["split=1", "split=2", "split=4", "step_split=1", "step_split=2", "wt=0", "wt=0,split=1",
+          "lds=1,block=256", "lds=1", "block=128", "block=256,step_split=1"]
+
+
+@pytest.mark.parametrize("policy", FORCED)
+def test_forced_launch_policies(policy, oracle_lib, monkeypatch):
+    """Every launch policy the library can be forced into through its ONE knob (OC_LAUNCH, read at
+    every call: csrc/oc_kernels.hip launch_policy) gives the oracle's results: a short seeded compare
+    of the fused wrapper step (salad-2) and of the base step (tl-3), specialised libraries, ragged
+    batch.  Under the driver's test run, not only in the builder's scratch runs."""
+    from gym_comm_amd import compiler
+    monkeypatch.setenv("OC_LAUNCH", policy)
+    n, steps, C = 1111, 90, 3
+    rng = np.random.default_rng(515)
+    lv = compiler.compile_level("full-divider_salad", 2, 40)
+    env = _env(lv, n, auto_reset=True, num_communication=C, fow_radius=1)
+    want = dict(kv.split("=") for kv in policy.split(","))
+    if "split" in want and want.get("wt", "1") == "1" and "lds" not in want:
+        assert env.launch_waves(general=False) == int(want["split"])
+    mv = scripted_then_random(rng, "full-divider_salad", steps, 2, n, nact=4)
+    cm = rng.integers(0, C, (steps, 2, n)).astype(np.int32)
+    acts = np.stack([mv[:, 0], cm[:, 0], mv[:, 1], cm[:, 1]], axis=1).astype(np.int32)
+    ora = oracle_lib.OracleBatch(lv.blob, n, threads=4)
+    comm = np.zeros((2, n), np.int32)
+    a_d = torch.from_numpy(acts).cuda()
+    for k in range(steps):
+        o, t, r, d = env.multi_step(a_d[k])
+        oo, to, ro, do = ora.multi_step(acts[k], comm, 1, 0, C, auto_reset=True)
+        assert np.array_equal(o.cpu().numpy(), oo), (policy, k)
+        assert np.array_equal(bits(r.cpu().numpy()), bits(ro)) and np.array_equal(d.cpu().numpy(), do), (policy, k)
+        assert np.array_equal(bits(t.cpu().numpy()), bits(to)), (policy, k)
+    assert_snapshots_equal(env.snapshot(), ora.snapshot_all(), policy)
+    assert env.read_metrics()["env_steps"] == n * steps
+    lv3 = compiler.compile_level("partial-divider_tl", 3, 40)
+    env3 = _env(lv3, n, auto_reset=True)
+    acts3 = scripted_then_random(rng, "partial-divider_tl", steps, 3, n)
+    ora3 = oracle_lib.OracleBatch(lv3.blob, n, threads=4)
+    a3 = torch.from_numpy(acts3).cuda()
+    for k in range(steps):
+        r, d, sh = env3.step(a3[k])
+        ro, do, sho = ora3.step(acts3[k], auto_reset=True)
+        clean = ora3.snapshot_all()["error"] == 0
+        assert np.array_equal(r.cpu().numpy()[clean], ro[clean]) and np.array_equal(d.cpu().numpy()[clean], do[clean]), (policy, k)
+        assert np.array_equal(bits(sh.cpu().numpy())[:, clean], bits(sho)[:, clean]), (policy, k)
+    hs, os_ = env3.snapshot(), ora3.snapshot_all()
+    assert_snapshots_equal(hs, os_, policy, where=(os_["error"] == 0) & (hs["error"] == 0))

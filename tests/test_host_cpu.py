@@ -105,14 +105,25 @@ def test_c_abi_exports_every_declared_symbol():
     bad = np.zeros(32, np.int32)
     h = ctypes.c_void_p()
     assert L.oc_level_create(bad.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 32, ctypes.byref(h)) == -1
-    # launch policy of the fused step (host only): four waves per 64 envs up to 24576 envs, two up
-    # to 32768, one beyond; the caller's hint overrides
-    if "OC_SPLIT" not in os.environ:
-        assert [L.oc_multi_step_waves(n, 0) for n in (1, 4096, 24576, 24577, 32768, 32769, 131072)] == \
-            [4, 4, 4, 2, 2, 1, 1]
-        assert L.oc_multi_step_waves(4096, 2) == 2
-        assert L.oc_multi_step_waves(4096, 1) == 1 and L.oc_multi_step_waves(131072, 4) == 4
-        assert L.oc_multi_step_waves(4096, 7) == 4 and L.oc_multi_step_waves(131072, -3) == 1
+    # launch policy of the fused step (host only): four waves per 64 envs up to 32768 envs, one beyond;
+    # the caller's hint overrides; the value is the launch the library really takes -- the generic
+    # library splits the plain variant four ways and nothing else
+    if "OC_LAUNCH" not in os.environ:
+        assert [L.oc_multi_step_waves(n, 0, 0) for n in (1, 4096, 32768, 32769, 131072)] == [4, 4, 4, 1, 1]
+        assert [L.oc_multi_step_waves(n, 0, 1) for n in (1, 4096, 32768, 32769)] == [1, 1, 1, 1]      # generic library
+        assert L.oc_multi_step_waves(4096, 2, 0) == 1            # (no two-way split in the generic library)
+        assert L.oc_multi_step_waves(4096, 1, 0) == 1 and L.oc_multi_step_waves(131072, 4, 0) == 4
+        assert L.oc_multi_step_waves(4096, 7, 0) == 4 and L.oc_multi_step_waves(131072, -3, 0) == 1
+    # OC_LAUNCH (one knob, read at every call) forces the policy
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); from gym_comm_amd import _lib; L = _lib.load(); "
+            "print(L.oc_multi_step_waves(131072, 0, 0), L.oc_multi_step_waves(4096, 0, 0))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OC_LAUNCH="split=4,wt=1"),
+                         capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["4", "4"], out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OC_LAUNCH="wt=0"),
+                         capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "1"], out                               # (the split launches store write-through)
 
 
 def test_policy_library_exports_its_header_and_packs_fragments_as_documented():

@@ -206,8 +206,8 @@ def test_closed_loop_in_one_launch_equals_policy_kernel_plus_step(n, level, C, o
     one = make(True, False)
     oneg = make(True, True)
     assert one[0]._b.kernel_flavour == "spec"
-    if "OC_SPLIT" not in os.environ:        # (a forced launch mode runs both cases the same way)
-        assert one[0]._b.launch_waves_per_64 == (4 if n <= 24576 else 1)
+    if "OC_LAUNCH" not in os.environ:       # (a forced launch mode runs both cases the same way)
+        assert one[0]._b.launch_waves(general=True) == (4 if n <= 32768 else 1)
     executed = []
     for k in range(9):
         two[3].step()

@@ -10,6 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 CFG = {"tomato_n4096": ("open-divider_tomato", 2, 4096, "k_multi_step"),
        "salad_n32768": ("full-divider_salad", 2, 32768, "k_multi_step"),
        "tl3_n65536": ("partial-divider_tl", 3, 65536, "k_step"),
@@ -23,6 +24,10 @@ def main():
     summ = os.path.join(ROOT, "tools", "summarize_profile.py")
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    # the kernel source these counters belong to: bench.py drops an entry whose digest is not the
+    # current source's (a stored constant must not outlive the kernel it was measured on)
+    from gym_comm_amd import specialize
+    digest = specialize._source_digest().hexdigest()[:16]
     for name, (level, A, n, kern) in CFG.items():
         sdir = os.path.join(src, "stats_" + name)
         if os.path.isdir(sdir):
@@ -41,7 +46,8 @@ def main():
             if h:
                 traffic["%s_a%d_n%d" % (level, A, n)] = {
                     "hbm_bytes_per_launch": h["total"], "fetch_corrected": h["fetch_corrected"],
-                    "write": h["write"], "source": "profiles/" + os.path.basename(out), "kernel": kern}
+                    "write": h["write"], "source": "profiles/" + os.path.basename(out), "kernel": kern,
+                    "kernel_source_digest": digest}
     json.dump(traffic, open(tpath, "w"), indent=1)
     print("updated", tpath)
 

@@ -24,7 +24,7 @@ def main():
                             num_communication=2, auto_reset=True, specialize_level=True,
                             waves_per_64=int(sys.argv[2]) if len(sys.argv) > 2 else 0,
                             episode_stats=len(sys.argv) > 3 and sys.argv[3] == "stats")   # rows + statistics: general variant
-    sp = env.launch_waves_per_64    # waves per 64 envs (4 = split launch): the kernel writes one record per wave
+    sp = env.launch_waves(general=len(sys.argv) > 3)    # waves per 64 envs (4 = split launch): the kernel writes one record per wave
     waves = (n + 63) // 64 * sp
     dbg = torch.zeros((waves, 16), dtype=torch.int64, device="cuda")
     env.reward = dbg.view(torch.int32)          # the stamps build writes its stamps through `sparse`
