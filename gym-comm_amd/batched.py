@@ -149,6 +149,16 @@ class BatchedOvercooked:
         """Waves per 64 envs the PLAIN fused step is launched with (1, 2 or 4 = split launches)."""
         return self.launch_waves(general=False)
 
+    @property
+    def standard_wrapper_config(self):
+        """The wrapper configuration of the reference's own run files (communication on, not ego-led,
+        both players CAN_MOVE, ego = sim agent 0, nobody BLIND, play off): what the plain step and
+        the options-on-the-standard-configuration variant of the fused kernel fold at compile time
+        (csrc/oc_kernels.hip: XO = 0 / 1); anything else runs the general variant."""
+        c = self._wrap_cfg
+        return bool(c.communication_on and not c.ego_led and c.can_move_mask == 3 and c.ego_agent_idx == 0
+                    and c.obs.blind_mask == 0 and not self.level.play)
+
     def launch_waves(self, general=False):
         """Waves per 64 envs the library launches for this batch (include/oc_hip.h:
         oc_multi_step_waves): the plain step, or -- ``general`` -- the general variant (pairs /

@@ -865,7 +865,6 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
     np[a] = sel(t_nonfloor[a] | oob, e.ap[a], tgt_p[a]);  // :551-559
   }
   P ex[A];
-  P may_share = 0;   // (A > 2) two agents may come to stand on one cell during this step: see the alias check below
 #pragma unroll
   for (int a = 0; a < A; a++) ex[a] = -1;
 #pragma unroll
@@ -875,18 +874,12 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
       const P same = p_eq(np[i], np[j]);  // :562-569
       const P i_stays = p_eq(np[i], e.ap[i]) & moving[i];
       const P j_stays = p_eq(np[j], e.ap[j]) & moving[j];
-      const P i_on_j = p_eq(e.ap[i], np[j]), j_on_i = p_eq(e.ap[j], np[i]);
-      const P swap = i_on_j & j_on_i;  // :572-575
+      const P swap = p_eq(e.ap[i], np[j]) & p_eq(e.ap[j], np[i]);  // :572-575
       const P block_i = sel(same, ~i_stays, swap);
       const P block_j = sel(same, i_stays | ~j_stays, swap);
       ex[i] &= ~block_i;
       ex[j] &= ~block_j;
-      if (A > 2) may_share |= same | i_on_j | j_on_i | p_eq(e.ap[i], e.ap[j]);
     }
-  // ONE wave ballot per step (a scalar read of a vector-written mask: ~16 cycles, see `hide`) decides
-  // whether any agent's interact() has to look for the World.remove alias corner at all: it needs
-  // two agents on one cell, and an agent is only ever on its old or its proposed cell
-  const bool wave_may_share = A > 2 && __ballot(may_share != 0) != 0;
 
   // ---- execute_navigation (:615-618): interact(), sequential in agent order ---
   // decision phase + one bit-field insert per item (utils/interact.py:4-75)
@@ -974,12 +967,17 @@ __device__ __forceinline__ void env_step(const Hdr &L, const RunCfg &R, const ui
       // Object that sits later in world order it removes the wrong one and the
       // reference's store is corrupt from here on.  Flag it.
       // Only reachable when another agent stands on this agent's cell (the 3-agent overlap
-      // quirk of check_collisions) while this one merges.
-      if (wave_may_share) {   // uniform, decided before the first interact()
-        P shared = 0;
+      // quirk of check_collisions) while this one merges: one ballot skips the item scan for
+      // the whole wave in every other step.
+      // (Tried: ONE ballot per step on "two agents may come to share a cell" -- any pair with equal
+      // old or proposed cells -- instead of one per agent: true in nearly every wave of 64 three-agent
+      // envs, so the scan below ran always: tl-3 x 65 536 3.82 -> 4.16 us.  The ballot per agent costs
+      // a scalar read of a vector-written mask, ~16 cycles, and is almost never taken.)
+      P shared = 0;
 #pragma unroll
-        for (int b = 0; b < A; b++)
-          if (b != a) shared |= p_eq(e.ap[b], pa);
+      for (int b = 0; b < A; b++)
+        if (b != a) shared |= p_eq(e.ap[b], pa);
+      if (__ballot((shared & do_merge) != 0) != 0) {
         P alias = 0;
 #pragma unroll
         for (int j = 0; j < M; j++) {
@@ -1698,11 +1696,17 @@ struct MultiArgs {
 };
 
 // OvercookedMultiEnv.multi_step (gym_comm/envs/overcooked_env.py:207-282), 2 agents.
-// XO = false: the plain step in the wrapper's standard configuration -- actions from the four
+// XO = 0: the plain step in the wrapper's standard configuration -- actions from the four
 // rows, no episode statistics (`p.opt` is not even looked at), communication on, not ego-led,
-// both players CAN_MOVE, ego = sim agent 0, nobody BLIND (the reference's env_args*.json and
-// BASELINE.md section 3) -- with those settings folded: no selects on them, no BLIND branch and
-// none of the register copies its join costs.  Anything else runs the general variant (XO = true).
+// both players CAN_MOVE, ego = sim agent 0, nobody BLIND, arglist.play off (the reference's
+// env_args*.json and BASELINE.md section 3) -- with those settings folded: no selects on them, no
+// BLIND branch and none of the register copies its join costs.
+// XO = 1: the same standard configuration, still folded, plus oc_step_opts' action sources
+// ([n][2] pairs, the in-kernel partner), episode statistics and the fused policies: what
+// OvercookedVecEnv launches with the reference's own run configurations (round 3: until then
+// every option landed in ONE general variant and step_tensors paid for run-time `play` and
+// wrapper-configuration selects it never uses -- specialised libraries only).
+// XO = 2: the general variant -- any wrapper configuration, arglist.play at run time, and the options.
 //
 // DUTY: which of the step's OUTPUTS this wave produces.  Everything up to done/reward is needed by
 // every output and is computed by every wave; what follows splits four ways:
@@ -1745,7 +1749,7 @@ __device__ __forceinline__ float *pol_lds_ts() {
 // one wave x 32 envs; a split workgroup gives each of its four waves one (viewer, half) pass
 // behind a second barrier ("every observation row of these 64 envs is written"), a lone wave
 // runs all four.
-template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int DUTY, bool SPLIT, bool POL = false>
+template <int M, bool LDS, int OT, bool WT, bool DUP, int XO, int DUTY, bool SPLIT, bool POL = false>
 __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int32_t *const actions_,
                                                 int32_t *const comm_, int64_t *const metrics_,
                                                 const int32_t n_, const int32_t block_, const void *const ego_src_,
@@ -1763,8 +1767,8 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
   const int i = SPLIT ? (int)blockIdx.x * 64 + (int)(threadIdx.x & 63)
                       : (int)blockIdx.x * (block_ & 0xFFFF) + (int)threadIdx.x;
   const bool valid = i < (int)n_;
-  const bool ego_from_pairs = XO && ((block_ >> 16) & 1), alt_from_pairs = XO && ((block_ >> 17) & 1),
-             alt_from_rng = XO && ((block_ >> 18) & 1), pairs64 = XO && ((block_ >> 19) & 1);
+  const bool ego_from_pairs = XO != 0 && ((block_ >> 16) & 1), alt_from_pairs = XO != 0 && ((block_ >> 17) & 1),
+             alt_from_rng = XO != 0 && ((block_ >> 18) & 1), pairs64 = XO != 0 && ((block_ >> 19) & 1);
 #ifdef OC_STAMPS
   unsigned long long oc_tt[16];
   for (int k = 0; k < 16; k++) oc_tt[k] = 0;
@@ -1846,7 +1850,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     // them now, under the wait for the state that has to be served anyway
     asm volatile("" ::"s"(tb.dist), "s"(p.obs), "s"(p.timestep), "s"(p.reward), "s"(p.done),
                  "s"(p.sparse), "s"(p.auto_reset), "s"(p.R.inv_T), "s"(p.R.inv_max_path));
-    if constexpr (XO) asm volatile("" ::"s"(p.opt.ep_return), "s"(p.opt.ep_length));
+    if constexpr (XO != 0) asm volatile("" ::"s"(p.opt.ep_return), "s"(p.opt.ep_length));
 #if defined(OC_SPECIALIZED) && !defined(OC_SPEC_GEOMETRY)
     // structure library: the map's geometry is a kernel argument; the first things the step
     // needs of it -- row length, tile planes, the Delivery tile -- are fetched here as well
@@ -1859,7 +1863,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     // retires in order, so the shaping's distance lookups then waited for them: 3.64 -> 3.90 us.)
     double ep_ret = 0.0;
     int ep_len = 0, prev_done = 0;
-    if (XO && p.opt.ep_return != nullptr) {   // uniform
+    if (XO != 0 && p.opt.ep_return != nullptr) {   // uniform
       const Rows er(p.opt.ep_return, n_, 1, i, 8);
       ep_ret = __builtin_bit_cast(double, (v2i)__builtin_amdgcn_raw_buffer_load_b64(er.rsrc, er.voff, 0, 0));
       ep_len = Rows(p.opt.ep_length, n_, 1, i).ld(0);
@@ -1888,9 +1892,10 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     OC_STAMP(1);   // state + actions arrived
     // comm one-hots (:227-246); an index the reference's one_hot[idx] = 1 would raise on is
     // flagged (OC_ERR_ACTION) and sends nothing
-    const bool cfg_comm_on = XO ? p.cfg.communication_on != 0 : true, cfg_ego_led = XO ? p.cfg.ego_led != 0 : false;
-    const int cfg_can_move = XO ? p.cfg.can_move_mask : 3, cfg_ego_idx = XO ? p.cfg.ego_agent_idx : 0;
-    const int cfg_blind = XO ? p.cfg.obs.blind_mask : 0;
+    // (XO == 2: any wrapper configuration; 0 and 1 run the standard one, folded)
+    const bool cfg_comm_on = XO == 2 ? p.cfg.communication_on != 0 : true, cfg_ego_led = XO == 2 ? p.cfg.ego_led != 0 : false;
+    const int cfg_can_move = XO == 2 ? p.cfg.can_move_mask : 3, cfg_ego_idx = XO == 2 ? p.cfg.ego_agent_idx : 0;
+    const int cfg_blind = XO == 2 ? p.cfg.obs.blind_mask : 0;
     const unsigned NC = (unsigned)p.cfg.obs.num_comm;
     // (per-lane predicates are P words, 0 / -1, see `hide`; the cfg_* tests are wave-uniform)
     const bool ego_talks = cfg_comm_on, alt_talks = cfg_comm_on && !cfg_ego_led;
@@ -1915,7 +1920,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     ShapeIn<2> sin;
     ShapeLoads<2> sld;
     // (the plain variant is only launched for play == 0; the general one reads the flag)
-    env_step<A, M, DUP, XO ? 2 : 0>(L, p.R, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
+    env_step<A, M, DUP, XO == 2 ? 2 : 0>(L, p.R, tb.dist, tb.probe, e, act, reward, done, success, sin, sld OC_STAMP_PASS);
     comp = e.completed;
     err = e.err != err_before;
     if constexpr (D_STATE) {
@@ -1986,7 +1991,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
       shaping_sum<2>(L, sin, sq, s0, s1 OC_STAMP_PASS);
       const double shaped = ((double)reward - s0) - s1;  // :282
       Out(p.reward, p.n, 1, i, 8).st_f64(0, shaped);
-      if (XO && p.opt.ep_return != nullptr) {   // uniform
+      if (XO != 0 && p.opt.ep_return != nullptr) {   // uniform
         Out(p.opt.ep_return, p.n, 1, i, 8).st_f64(0, prev_done ? shaped : ep_ret + shaped);
         Out(p.opt.ep_length, p.n, 1, i).st(0, prev_done ? 1 : ep_len + 1);
       }
@@ -1996,7 +2001,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
   if constexpr (D_STATE) slot.add(metrics_ != nullptr, valid, done, success, reward, comp, err);
   OC_STAMP(8);
   if constexpr (POL) {
-    static_assert(XO, "the fused policies belong to the general variant");
+    static_assert(XO != 0, "the fused policies belong to the variants with action sources");
     // split: every observation row (and the timestep) of this workgroup's 64 envs is in LDS;
     // a lone wave re-reads its own rows from memory
     if constexpr (SPLIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -2047,7 +2052,7 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
 // not on a pointer that a scalar load has yet to deliver; ego_src_ = opts.ego_pairs, alt_src_ =
 // opts.alt_rng or opts.alt_pairs: preloaded as well (n_ is 32 bits wide so that the lot fits the
 // 14 preloadable dwords), so the general variant issues its action loads with the state loads)
-template <int M, bool LDS, int OT, bool WT, bool DUP, bool XO, int SP, bool POL = false>
+template <int M, bool LDS, int OT, bool WT, bool DUP, int XO, int SP, bool POL = false>
 __global__ void __launch_bounds__(256) k_multi_step(int32_t *const state_, const int32_t *const actions_,
                                                     int32_t *const comm_, int64_t *const metrics_,
                                                     const int32_t n_, const int32_t block_,
@@ -2859,7 +2864,16 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   const bool wt = write_through(n);
   const bool std_cfg = cfg->communication_on && !cfg->ego_led && cfg->can_move_mask == 3 &&
                        cfg->ego_agent_idx == 0 && cfg->obs.blind_mask == 0 && !lv->run.play;
-  const bool xo = o.ep_return || o.ego_pairs || o.alt_pairs || o.alt_rng || !std_cfg;
+  const bool opts_used = o.ep_return || o.ego_pairs || o.alt_pairs || o.alt_rng;
+  const bool xo = opts_used || !std_cfg;
+#ifdef OC_SPECIALIZED
+  const bool x1 = opts_used && std_cfg;      // XO = 1: the options on the folded standard configuration
+#else
+  const bool x1 = false;                     // (the generic library: its build time)
+#endif
+  if (o.policy && !std_cfg)
+    return fail(OC_E_BADARG, "oc_multi_step: opts.policy runs on the wrapper's standard configuration (communication on, "
+                             "not ego-led, both CAN_MOVE, ego_agent_idx 0, nobody BLIND, play off); use oc_policy_mlp + oc_multi_step");
   const int sp = oc_multi_step_waves(n, o.waves_per_64, xo ? 1 : 0);   // (the launch actually taken, see there)
 #define OC_MS_X(MM, DD, XX)                                                           \
   do {                                                                                \
@@ -2880,9 +2894,9 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
 // (the generic library splits the plain variant only: its build time)
 #define OC_MS_SPLIT2(MM, DD)                                                                                 \
   do {                                                                                                       \
-    if (ot == 1) return launch_ms_split(k_multi_step<MM, false, 1, true, DD, false, 2>, 2, a, n, stream);    \
-    if (ot == 2) return launch_ms_split(k_multi_step<MM, false, 2, true, DD, false, 2>, 2, a, n, stream);    \
-    return launch_ms_split(k_multi_step<MM, false, 0, true, DD, false, 2>, 2, a, n, stream);                 \
+    if (ot == 1) return launch_ms_split(k_multi_step<MM, false, 1, true, DD, 0, 2>, 2, a, n, stream);    \
+    if (ot == 2) return launch_ms_split(k_multi_step<MM, false, 2, true, DD, 0, 2>, 2, a, n, stream);    \
+    return launch_ms_split(k_multi_step<MM, false, 0, true, DD, 0, 2>, 2, a, n, stream);                 \
   } while (0)
 #ifdef OC_SPECIALIZED
 // general variant + both policies evaluated behind the step (oc_step_opts.policy)
@@ -2890,27 +2904,29 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
   do {                                                                                                          \
     if (!wt || in_lds) return fail(OC_E_BADARG, "oc_multi_step: opts.policy needs write-through stores and tables in global memory"); \
     if (sp == 4) {                                                                                              \
-      if (ot == 1) return launch_ms_split(k_multi_step<MM, false, 1, true, DD, true, 4, true>, 4, a, n, stream); \
-      if (ot == 2) return launch_ms_split(k_multi_step<MM, false, 2, true, DD, true, 4, true>, 4, a, n, stream); \
-      return launch_ms_split(k_multi_step<MM, false, 0, true, DD, true, 4, true>, 4, a, n, stream);             \
+      if (ot == 1) return launch_ms_split(k_multi_step<MM, false, 1, true, DD, 1, 4, true>, 4, a, n, stream); \
+      if (ot == 2) return launch_ms_split(k_multi_step<MM, false, 2, true, DD, 1, 4, true>, 4, a, n, stream); \
+      return launch_ms_split(k_multi_step<MM, false, 0, true, DD, 1, 4, true>, 4, a, n, stream);             \
     }                                                                                                           \
-    if (ot == 1) return launch_ms(k_multi_step<MM, false, 1, true, DD, true, 1, true>, a, n, stream, 0);        \
-    if (ot == 2) return launch_ms(k_multi_step<MM, false, 2, true, DD, true, 1, true>, a, n, stream, 0);        \
-    return launch_ms(k_multi_step<MM, false, 0, true, DD, true, 1, true>, a, n, stream, 0);                     \
+    if (ot == 1) return launch_ms(k_multi_step<MM, false, 1, true, DD, 1, 1, true>, a, n, stream, 0);        \
+    if (ot == 2) return launch_ms(k_multi_step<MM, false, 2, true, DD, 1, 1, true>, a, n, stream, 0);        \
+    return launch_ms(k_multi_step<MM, false, 0, true, DD, 1, 1, true>, a, n, stream, 0);                     \
   } while (0)
 #define OC_MS_SPLIT_BOTH(MM, DD)                   \
   if (o.policy) OC_MS_POL(MM, DD);                 \
-  if (xo && sp == 4) OC_MS_SPLIT(MM, DD, true);    \
-  if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, false);  \
-  if (!xo && sp == 2) OC_MS_SPLIT2(MM, DD)
+  if (x1 && sp == 4) OC_MS_SPLIT(MM, DD, 1);       \
+  if (xo && sp == 4) OC_MS_SPLIT(MM, DD, 2);       \
+  if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, 0);      \
+  if (!xo && sp == 2) OC_MS_SPLIT2(MM, DD);        \
+  if (x1) OC_MS_X(MM, DD, 1)
 #else
-#define OC_MS_SPLIT_BOTH(MM, DD) if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, false)
+#define OC_MS_SPLIT_BOTH(MM, DD) if (!xo && sp == 4) OC_MS_SPLIT(MM, DD, 0)
 #endif
 #define OC_MS(MM, DD)                            \
   do {                                           \
     OC_MS_SPLIT_BOTH(MM, DD);                    \
-    if (xo) OC_MS_X(MM, DD, true);               \
-    OC_MS_X(MM, DD, false);                      \
+    if (xo) OC_MS_X(MM, DD, 2);                  \
+    OC_MS_X(MM, DD, 0);                          \
   } while (0)
 #ifdef OC_SPECIALIZED
   OC_MS(OC_SPEC_HDR.M, OC_SPEC_DUP);

@@ -548,9 +548,11 @@ class ClosedLoop:
         # passes back to back (9.6 -> 13.7 us at 32 768 envs), so larger batches keep two launches
         pt = venv.partner
         can = (isinstance(ego, FusedMLPPartner) and isinstance(pt, FusedMLPPartner) and pt.F == ego.F
-               and pt.C == ego.C and ego.C <= 4 and venv._b.kernel_flavour == "spec")
+               and pt.C == ego.C and ego.C <= 4 and venv._b.kernel_flavour == "spec"
+               and venv._b.standard_wrapper_config)
         if one_launch and not can:
-            raise ValueError("one_launch needs two FusedMLPPartner of one shape, C <= 4 and a specialised library")
+            raise ValueError("one_launch needs two FusedMLPPartner of one shape, C <= 4, a specialised library "
+                             "and the wrapper's standard configuration")
         self.one_launch = (can and venv._b.launch_waves(general=True) == 4) if one_launch is None else bool(one_launch)
         self._primed = False
         self.prime()
