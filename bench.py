@@ -269,6 +269,19 @@ def reference_python_rate(level, agents, wrapper):
         return None
 
 
+def timeline_reduce(rec):
+    """Per-launch reduction of a timeline record tensor (include/oc_hip.h: oc_timeline_begin), int32
+    [launches][stride][4] = {start lo, start hi, issue-span | drain-span << 16, shader cycles} per
+    wave, 0xFF-filled where no wave wrote.  Returns int64 tensors: wrote [L][stride] (bool), start
+    [L][stride], and per wave issue-end, drain-end (absolute ticks) and shader cycles."""
+    r = rec.to(torch.int64) & 0xFFFFFFFF
+    start = r[:, :, 0] | (r[:, :, 1] << 32)
+    wrote = ~((r[:, :, 0] == 0xFFFFFFFF) & (r[:, :, 1] == 0xFFFFFFFF))
+    issue = start + (r[:, :, 2] & 0xFFFF)
+    drain = start + (r[:, :, 2] >> 16)
+    return wrote, start, issue, drain, r[:, :, 3]
+
+
 def _timeline_run(args, dev, seed, stream, steps, variant, min_ms):
     """One timeline flavour of the level's library: capture `steps` launches with a record each,
     replay for >= min_ms of GPU time; returns per-launch arrays (10 ns ticks) and per-wave means."""
@@ -276,12 +289,10 @@ def _timeline_run(args, dev, seed, stream, steps, variant, min_ms):
     env, step_fn, _ = open_loop_workload(args, dev, seed, specialize_level=variant)
     L = env._L
     n = args.envs
-    BIG = torch.iinfo(torch.int64).max                # (the stamps are far below 2^63: signed min/max is fine)
+    BIG = torch.iinfo(torch.int64).max
     stride = 4 * ((n + 63) // 64)                     # an upper bound of the waves of one launch
-    rec = torch.zeros((steps, 4, stride), dtype=torch.int64, device=dev)
-    init = torch.zeros((steps, 4, stride), dtype=torch.int64, device=dev)
-    init[:, 0] = BIG
-    end_row = 2 if variant == "timeline-drain" else 1
+    rec = torch.zeros((steps, stride, 4), dtype=torch.int32, device=dev)
+    use_drain = variant == "timeline-drain"
     out = {k: [] for k in ("start", "end", "issue", "life", "spread", "mhz", "ev_us")}
     with torch.cuda.stream(stream):
         for k in range(8):
@@ -303,21 +314,23 @@ def _timeline_run(args, dev, seed, stream, steps, variant, min_ms):
         t_end = time.perf_counter() + 10.0
         gpu_ms = 0.0
         while gpu_ms < min_ms and time.perf_counter() < t_end:
-            rec.copy_(init)
+            rec.fill_(-1)
             stream.synchronize()
             e0.record(stream)
             g.replay()
             e1.record(stream)
             stream.synchronize()
-            wrote = rec[:, 0] != BIG
-            start = rec[:, 0].min(dim=1).values        # per launch, over the waves that wrote
+            wrote, st, issue, drain, cycles = timeline_reduce(rec)
+            end_w = drain if use_drain else issue
+            start = torch.where(wrote, st, torch.full_like(st, BIG)).min(dim=1).values   # per launch
+            end = torch.where(wrote, end_w, torch.zeros_like(st)).max(dim=1).values
             out["start"].append(start.cpu().numpy())
-            out["end"].append(rec[:, end_row].max(dim=1).values.cpu().numpy())
-            out["issue"].append(rec[:, 1].max(dim=1).values.cpu().numpy())
-            span = ((rec[:, end_row] - rec[:, 0]) * wrote).sum().double()
+            out["end"].append(end.cpu().numpy())
+            out["issue"].append(torch.where(wrote, issue, torch.zeros_like(st)).max(dim=1).values.cpu().numpy())
+            span = ((end_w - st) * wrote).sum().double()
             out["life"].append(float(span.item()) / max(1, int(wrote.sum().item())))
-            out["mhz"].append(100.0 * float(rec[:, 3].sum().item()) / max(1.0, float(span.item())))
-            out["spread"].append(float((torch.where(wrote, rec[:, 0], start.unsqueeze(1)).max(dim=1).values - start)
+            out["mhz"].append(100.0 * float((cycles * wrote).sum().item()) / max(1.0, float(span.item())))
+            out["spread"].append(float((torch.where(wrote, st, start.unsqueeze(1)).max(dim=1).values - start)
                                        .double().mean().item()))
             ms = e0.elapsed_time(e1)
             gpu_ms += ms
@@ -328,19 +341,19 @@ def _timeline_run(args, dev, seed, stream, steps, variant, min_ms):
         wpw = max(1, out["waves"] // max(1, (n + 63) // 64))
         out["by_wave_in_workgroup"] = []
         for j in range(wpw):
-            sel = rec[:, :, j:out["waves"]:wpw]
+            sl = slice(j, out["waves"], wpw)
             out["by_wave_in_workgroup"].append({
-                "start_us": float((sel[:, 0] - start.unsqueeze(1)).double().mean().item()) * 0.01,
-                "end_us": float((sel[:, end_row] - start.unsqueeze(1)).double().mean().item()) * 0.01})
+                "start_us": float((st[:, sl] - start.unsqueeze(1)).double().mean().item()) * 0.01,
+                "end_us": float((end_w[:, sl] - start.unsqueeze(1)).double().mean().item()) * 0.01})
     return out
 
 
 def decompose_step(args, dev, seed, stream, steps, min_ms=60.0):
     """Split a step of the chained-launch graph into KERNEL-ACTIVE time and LAUNCH BOUNDARY without a
     profiler: the same workload on the TIMELINE build of the level's library (-DOC_TIMELINE=1: the
-    product source + two reads of the chip-wide constant-rate clock and four write-through stores
-    by one lane per wave), one `steps`-launch hipGraph whose launches each have their own record
-    [4][waves]; reduced over the waves.  Per launch k:
+    product source + two reads of the chip-wide constant-rate clock and ONE 16-byte write-through
+    store by one lane per wave), one `steps`-launch hipGraph whose launches each have their own record
+    [waves][4 x 32 bits]; reduced over the waves.  Per launch k:
         active_k   = max issue-end_k - min start_k        waves of launch k on the chip
         boundary_k = min start_{k+1} - max issue-end_k     store drain, end-of-kernel cache work, the
                                                            command processor, the next dispatch
@@ -687,9 +700,16 @@ def main():
             if decomp is not None:
                 # the step as the chip saw it (timeline build): kernel-active + boundary = period, to be
                 # read against ms_per_step of the product build above
+                # The stamps cost the timeline build's waves an SMEM round trip at their very end (the
+                # clock read has to come back before it can be stored), so ITS kernel-active span is an
+                # upper bound for the product kernel's; the boundary -- store drain, end-of-kernel cache
+                # work, command processor, dispatch -- does not depend on the stamps.  Hence also:
+                # product step - boundary = the product kernel's active span.
+                act_prod = med_step_s * 1e6 - decomp["boundary_us"]
                 out["roofline"].update({
                     "kernel_active_us": decomp["kernel_active_us"], "boundary_us": decomp["boundary_us"],
-                    "frac_kernel_active": (rd + wr) * n / (decomp["kernel_active_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                    "kernel_active_us_product": act_prod,
+                    "frac_kernel_active": (rd + wr) * n / (act_prod * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                     "decompose": decomp,
                     "decompose_closure": (decomp["kernel_active_us"] + decomp["boundary_us"]) / (med_step_s * 1e6)})
         if not args.no_cpu_baseline and world == 1 and not closed:

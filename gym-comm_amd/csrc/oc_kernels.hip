@@ -126,17 +126,18 @@ struct RunCfg {
 // k_multi_step reads the constant-rate 100 MHz counter (s_memrealtime: the same clock on every XCD,
 // unlike the per-XCD shader clock of s_memtime) when it starts and when its last instruction has
 // been issued, and lane 0 writes them -- and the wave's lifetime in shader-clock cycles -- to the
-// wave's OWN words of the launch's record, uint64 [4][stride].  A graph of chained launches
+// wave's OWN 16 bytes of the launch's record, uint32 [stride][4].  A graph of chained launches
 // replayed on such a build yields, per launch, the span in which the kernel had waves on the chip
 // ("kernel-active") and the gap to the next launch's first wave (the launch boundary: store drain,
 // end-of-kernel cache work, the command processor, the next dispatch) -- the split of ms_per_step
 // that bench.py --decompose reports, without a profiler attached (include/oc_hip.h:
 // oc_timeline_begin).  -DOC_TIMELINE=2 additionally waits for the wave's stores (s_waitcnt
 // vmcnt(0)) and stamps that too: how much of the boundary is store drain.
-// Two earlier forms perturbed what they measured: same-address atomics (4 x 256 waves on one
-// line: 14.6 us per launch instead of 3.1), and a store wait + default-policy stamp stores in every
-// wave (+0.45 us: the wave outlives its stores and leaves dirty lines for the end-of-kernel
-// write-back); the stamp stores are write-through (sc1) like the step's own.
+// Earlier forms perturbed what they measured: same-address atomics (4 x 256 waves on one line:
+// 14.6 us per launch instead of 3.1); a store wait + default-policy stamp stores in every wave
+// (+0.45 us: the wave outlives its stores and leaves dirty lines for the end-of-kernel write-back);
+// four 8-byte write-through stores per wave (+0.2 us at 4 096 envs, +1 us at 131 072).  Now: ONE
+// 16-byte write-through store per wave.
 #define OC_TL_BEGIN()                                                            \
   const unsigned long long oc_tl0_ = __builtin_amdgcn_s_memrealtime();           \
   const unsigned long long oc_tc0_ = __builtin_amdgcn_s_memtime()
@@ -144,7 +145,7 @@ struct RunCfg {
   do {                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     const unsigned long long oc_tl1_ = __builtin_amdgcn_s_memrealtime();                         \
-    unsigned long long oc_tl2_ = 0;                                                              \
+    unsigned long long oc_tl2_ = oc_tl1_;                                                        \
     if (OC_TIMELINE >= 2) {                                                                      \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
       oc_tl2_ = __builtin_amdgcn_s_memrealtime();                                                \
@@ -152,15 +153,19 @@ struct RunCfg {
     const unsigned long long oc_tc2_ = __builtin_amdgcn_s_memtime();                             \
     unsigned long long *tl_ = (ptr_);                                                            \
     if (tl_ != nullptr && (threadIdx.x & 63) == 0) {                                             \
-      typedef int v2i_ __attribute__((ext_vector_type(2)));                                      \
+      /* ONE 16-byte write-through store per wave: {start (64 bits), issue-end - start | (drain-end  \
+         - start) << 16, shader cycles}; spans are < 65 536 ticks (655 us) */                     \
+      typedef int v4i_ __attribute__((ext_vector_type(4)));                                      \
       const int64_t w_ = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);           \
       const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc(tl_, 0, 0x7FFFFFFF, 0x00020000); \
-      const int sb_ = (int)(stride_) * 8;                                                        \
-      const unsigned long long cyc_ = oc_tc2_ - oc_tc0_;                                         \
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_, oc_tl0_), r_, (int)w_ * 8, 0, 16);       \
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_, oc_tl1_), r_, (int)w_ * 8, sb_, 16);     \
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_, oc_tl2_), r_, (int)w_ * 8, 2 * sb_, 16); \
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_, cyc_), r_, (int)w_ * 8, 3 * sb_, 16);    \
+      const unsigned d1_ = (unsigned)min((unsigned long long)0xFFFF, oc_tl1_ - oc_tl0_);         \
+      const unsigned d2_ = (unsigned)min((unsigned long long)0xFFFF, oc_tl2_ - oc_tl0_);         \
+      v4i_ q_;                                                                                   \
+      q_.x = (int)(unsigned)oc_tl0_;                                                             \
+      q_.y = (int)(unsigned)(oc_tl0_ >> 32);                                                     \
+      q_.z = (int)(d1_ | (d2_ << 16));                                                           \
+      q_.w = (int)(unsigned)(oc_tc2_ - oc_tc0_);                                                 \
+      __builtin_amdgcn_raw_buffer_store_b128(q_, r_, (int)w_ * 16, 0, 16);                       \
     }                                                                                            \
   } while (0)
 #else
@@ -1795,6 +1800,9 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
                         (int)threadIdx.x & 63, p.pol_ksteps);
   }
   if (valid) {
+    // (Tried: the state loads ahead of this tail-lane test -- v_cmp -> s_and_saveexec costs ~16 cycles
+    // in front of the first load.  Nothing at 4 096 envs, and salad-2 x 32 768, two waves per SIMD,
+    // went from 3.96 to 4.34 us: the shaping wave of a workgroup ended 0.2 us later.  Left as it was.)
     constexpr int WS = state_words<A, M, DUP>();
     const Out st(state_, n_, WS, i), cm(comm_, n_, 2, i);
     int32_t w[WS];
@@ -2115,7 +2123,7 @@ unsigned long long *timeline_next(int64_t waves, int64_t &stride) {
 #ifdef OC_TIMELINE
   if (g_timeline_left > 0 && waves <= g_timeline_stride) {
     unsigned long long *r = g_timeline;
-    g_timeline += 4 * g_timeline_stride;
+    g_timeline += 2 * g_timeline_stride;   // 16 bytes per wave
     g_timeline_left--;
     stride = g_timeline_stride;
     return r;
@@ -2869,7 +2877,7 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
 #ifdef OC_SPECIALIZED
   const bool x1 = opts_used && std_cfg;      // XO = 1: the options on the folded standard configuration
 #else
-  const bool x1 = false;                     // (the generic library: its build time)
+  [[maybe_unused]] const bool x1 = false;    // (the generic library: its build time)
 #endif
   if (o.policy && !std_cfg)
     return fail(OC_E_BADARG, "oc_multi_step: opts.policy runs on the wrapper's standard configuration (communication on, "

@@ -9,18 +9,22 @@ uniform branches and fully unrolled loops.  The result is an ordinary shared lib
 exporting the same C ABI (include/oc_hip.h).  Two flavours:
 
   "level" library      (``-DOC_SPEC_GEOMETRY``) folds everything, the map included: the
-                       fastest code (3.64 us per step, tomato-2 x 4096 envs), for ONE map;
+                       fastest code (2.82 us per step, tomato-2 x 4096 envs), for ONE map;
   "structure" library  folds what the recipes, the item multiset, the agent count and the
                        border kind fix; the map (size, tiles, positions) stays a run-time
-                       argument (3.82 us).  It serves EVERY map of that structure -- e.g. a
+                       argument (~4 % slower).  It serves EVERY map of that structure -- e.g. a
                        user-made map with the Salad recipe on a box that has no hipcc, which
-                       the generic library would step at 7.3 us.
+                       the generic library would step ~1.8x slower.
+(Round-3 figures; the ratios level : structure : generic were 3.07 : 3.18 :
+5.55 us in round 2.)
 
 ``load_for`` picks, in this order: the cached level library; the cached structure library;
 a level library compiled now (hipcc present, no profiler attached); the generic library.
 Libraries are cached in csrc/_spec/ under a hash of (generated header, kernel source,
-C headers, flags) -- built by ``__graft_entry__.build()`` for every shipped level (both
-flavours) and travelling with the repo snapshot.  max_num_timesteps, the ALLERGIC flags
+C headers, flags) -- built by ``__graft_entry__.build()`` (structure libraries for every shipped
+level, level libraries for the BASELINE configs and the tested levels) and travelling with the repo
+snapshot.  Measurement variants of a level library (``variant="timeline"``: -DOC_TIMELINE, bench.py
+--decompose) are never picked unless asked for.  max_num_timesteps, the ALLERGIC flags
 and the subtask order stay run-time arguments and select nothing.
 """
 import ctypes

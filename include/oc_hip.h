@@ -270,17 +270,19 @@ OC_API int32_t oc_multi_step_waves(int64_t n, int32_t hint, int32_t general_vari
  * 100 MHz) at its start and after its last instruction (-DOC_TIMELINE=2, variant
  * "timeline-drain": also after an added wait for its last store); the next `count` calls of
  * oc_step / oc_multi_step -- eager or captured into a hipGraph -- each get one record of `records`
- * (DEVICE memory, uint64 [count][4][stride]) into which wave w of the launch (w = workgroup * waves
- * per workgroup + wave, < 4 * ceil(n / 64) <= stride) stores
- *   [0][w] start   [1][w] issue-end   [2][w] drain-end (0 unless OC_TIMELINE=2)
- *   [3][w] shader-clock cycles (s_memtime) from start to the last stamp: against the realtime
- *          span it gives the shader clock the wave ran at
- * (write-through stores to the wave's own words; a launch with fewer waves leaves the rest
- * untouched, so the caller fills [0] with ~0 and [1..3] with 0 before every run and reduces
- * min / max over w).  Per launch, max issue-end - min start is the span with waves on the chip
- * ("kernel-active"), the next launch's min start - max issue-end the launch boundary (store drain,
- * end-of-kernel cache work, command processor, dispatch); bench.py --decompose reports both beside
- * the unchanged headline.  No reference analogue.  records = NULL, count = 0 stops the recording. */
+ * (DEVICE memory, uint32 [count][stride][4]) into which wave w of the launch (w = workgroup * waves
+ * per workgroup + wave, < 4 * ceil(n / 64) <= stride) stores its 16 bytes with ONE write-through store:
+ *   [w][0], [w][1]  start, low and high word (64-bit tick count)
+ *   [w][2]          issue-end - start in bits 0..15, drain-end - start in bits 16..31 (ticks, saturated
+ *                   at 65 535 = 655 us; drain = issue unless OC_TIMELINE=2)
+ *   [w][3]          shader-clock cycles (s_memtime) from start to the last stamp: against the realtime
+ *                   span it gives the shader clock the wave ran at
+ * A launch with fewer waves leaves the rest untouched, so the caller fills the records with 0xFF
+ * before every run (a start of ~0 = "no wave") and reduces min start / max end over w.  Per launch,
+ * max issue-end - min start is the span with waves on the chip ("kernel-active"), the next launch's
+ * min start - max issue-end the launch boundary (store drain, end-of-kernel cache work, command
+ * processor, dispatch); bench.py --decompose reports both beside the unchanged headline.  No
+ * reference analogue.  records = NULL, count = 0 stops the recording. */
 OC_API int oc_timeline_begin(uint64_t *records, int64_t count, int64_t stride);
 
 /* Uniform random (move, comm) indices for one player of every env, written straight into two

@@ -211,8 +211,7 @@ def test_timeline_build_records_every_launch_and_steps_identically():
     acts[:, 0] = torch.randint(0, 4, (steps, n), dtype=torch.int32, device="cuda")
     acts[:, 2] = torch.randint(0, 4, (steps, n), dtype=torch.int32, device="cuda")
     stride = 4 * (n // 64)
-    rec = torch.zeros((steps, 4, stride), dtype=torch.int64, device="cuda")
-    rec[:, 0] = -1
+    rec = torch.full((steps, stride, 4), -1, dtype=torch.int32, device="cuda")
     assert tl._L.oc_timeline_begin(ctypes.c_void_p(rec.data_ptr()), steps, stride) == 0
     for k in range(steps):
         prod.multi_step(acts[k])
@@ -224,13 +223,13 @@ def test_timeline_build_records_every_launch_and_steps_identically():
     for name in ("state", "obs", "comm", "done", "reward"):
         assert torch.equal(getattr(prod, name), getattr(tl, name)), name
     assert torch.equal(prod.shaped_reward.view(torch.int64), tl.shaped_reward.view(torch.int64))
-    r = rec.cpu().numpy()
+    wrote, start, issue, drain, cycles = (t.cpu().numpy() for t in _bench().timeline_reduce(rec))
     waves = (n // 64) * tl.launch_waves_per_64
-    assert (r[:, 0, :waves] > 0).all() and (r[:, 0, waves:] == -1).all() and (r[:, 1:, waves:] == 0).all()
-    r = r[:, :, :waves]
-    mhz = 100.0 * r[:, 3].sum() / (r[:, 1] - r[:, 0]).sum()
+    assert wrote[:, :waves].all() and not wrote[:, waves:].any()
+    start, issue, drain, cycles = (a[:, :waves] for a in (start, issue, drain, cycles))
+    assert (start > 0).all() and (start <= issue).all() and (issue == drain).all()   # (drain: the =2 flavour only)
+    mhz = 100.0 * cycles.sum() / (issue - start).sum()
     assert 500 < mhz < 3000, mhz                            # the shader clock the waves ran at
-    assert (r[:, 0] <= r[:, 1]).all() and (r[:, 2] == 0).all()       # (drain-end: the =2 flavour only)
-    start, end = r[:, 0].min(axis=1), r[:, 1].max(axis=1)
-    assert (start[1:] >= end[:-1]).all()                     # launches of one stream do not overlap
-    assert ((end - start) < 100000).all()                    # < 1 ms at 100 MHz
+    first, last = start.min(axis=1), issue.max(axis=1)
+    assert (first[1:] >= last[:-1]).all()                    # launches of one stream do not overlap
+    assert ((last - first) < 100000).all()                   # < 1 ms at 100 MHz

@@ -8,6 +8,7 @@ b open-divider_tomato_4096                                   # the default: BASE
 b tomato_4096_steps20 --steps 20 --warmup 5 --no-cpu-baseline    # the driver's form
 b tomato_4096_steps20000 --steps 20000 --no-cpu-baseline
 b tomato_4096_one_wave --waves-per-64 1 --no-cpu-baseline        # the launch the split replaced
+b tomato_4096_decompose --steps 20 --warmup 5 --decompose --no-cpu-baseline
 b full-divider_salad_32768 --level full-divider_salad --envs 32768 --no-cpu-baseline
 b partial-divider_tl_65536 --level partial-divider_tl --agents 3 --envs 65536 --no-cpu-baseline
 b open-divider_tomato_131072 --envs 131072 --no-cpu-baseline

@@ -9,8 +9,8 @@ d() { name=$1; shift; python bench.py "$@" --steps 20 --warmup 5 --decompose --n
 import json, sys
 d = json.loads(open(sys.argv[1]).read()); r = d["roofline"]
 dd = r["decompose"]
-print("%-16s step %.3f us | timeline build %.3f: active %.3f + boundary %.3f = %.3f (closure %.3f) | drain %s | wave life %.3f spread %.3f clock %.0f MHz | frac %.4f frac_active %.4f"
-      % (sys.argv[2], d["ms_per_step"] * 1e3, dd["timeline_build_event_us_per_step"], r["kernel_active_us"],
+print("%-16s step %.3f us = active %.3f + boundary %.3f | timeline build %.3f: active %.3f + boundary %.3f = %.3f (closure %.3f) | drain %s | wave life %.3f spread %.3f clock %.0f MHz | frac %.4f frac_active %.4f"
+      % (sys.argv[2], d["ms_per_step"] * 1e3, r["kernel_active_us_product"], r["boundary_us"], dd["timeline_build_event_us_per_step"], r["kernel_active_us"],
          r["boundary_us"], dd["period_us"], r["decompose_closure"], dd["store_drain_us"], dd["wave_lifetime_us"],
          dd["wave_start_spread_us"], dd["shader_clock_mhz"], r["frac"], r["frac_kernel_active"]))
 print("                 waves of a workgroup, start..end us after the launch's first wave: " + "  ".join("%.2f..%.2f" % (w["start_us"], w["end_us"]) for w in dd["by_wave_in_workgroup"]))

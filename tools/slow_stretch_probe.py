@@ -55,9 +55,7 @@ class Probe:
         self.env = BatchedOvercooked("open-divider_tomato", num_envs=N, max_num_timesteps=500, device="cuda:0",
                                      specialize_level="timeline")
         self.stride = 4 * ((N + 63) // 64)
-        self.rec = torch.zeros((STEPS, 4, self.stride), dtype=torch.int64, device="cuda")
-        self.init = torch.zeros_like(self.rec)
-        self.init[:, 0] = BIG
+        self.rec = torch.zeros((STEPS, self.stride, 4), dtype=torch.int32, device="cuda")
         acts = torch.randint(0, 2, (16, 4, N), dtype=torch.int32, device="cuda")
         acts[:, 0] = torch.randint(0, 4, (16, N), dtype=torch.int32, device="cuda")
         acts[:, 2] = torch.randint(0, 4, (16, N), dtype=torch.int32, device="cuda")
@@ -79,18 +77,18 @@ class Probe:
 
     def replay(self, tag):
         with torch.cuda.stream(self.stream):
-            self.rec.copy_(self.init)
+            self.rec.fill_(-1)
             self.stream.synchronize()
             t0 = time.perf_counter()
             self.graph.replay()
             self.stream.synchronize()
             wall = time.perf_counter() - t0
-            rec = self.rec
-            wrote = rec[:, 0] != BIG
-            start = rec[:, 0].min(dim=1).values
-            end = rec[:, 2].max(dim=1).values
-            span = ((rec[:, 2] - rec[:, 0]) * wrote).sum(dim=1).double()
-            cyc = rec[:, 3].sum(dim=1).double()
+            import bench
+            wrote, st, issue, _, cycles = bench.timeline_reduce(self.rec)
+            start = torch.where(wrote, st, torch.full_like(st, BIG)).min(dim=1).values
+            end = torch.where(wrote, issue, torch.zeros_like(st)).max(dim=1).values
+            span = ((issue - st) * wrote).sum(dim=1).double()
+            cyc = (cycles * wrote).sum(dim=1).double()
             s, e = start.cpu().numpy(), end.cpu().numpy()
             mhz = (100.0 * cyc / span.clamp(min=1)).cpu().numpy()
             cpw = (cyc / wrote.sum(dim=1).clamp(min=1)).cpu().numpy()          # shader cycles per wave
