@@ -30,6 +30,11 @@ sometimes returns 50-80 ms after the device has finished (tools/slow_stretch_pro
 round 2 took for a "slow stretch" of the GPU and hid behind 150 ms of untimed replays.  A short
 untimed settle (``--settle-ms``, 30 ms: the first replays of a freshly instantiated graph) remains.
 
+``--decompose`` replays the same graph on the TIMELINE build of the level's library (every wave
+stamps the chip-wide 100 MHz clock; include/oc_hip.h: oc_timeline_begin) and adds
+``roofline.kernel_active_us`` / ``boundary_us`` / ``frac_kernel_active`` beside the unchanged
+headline: the step split into the span with waves on the chip and the launch boundary, no profiler.
+
 ``--mode closed-loop`` measures the same kernel with policies in the loop (an ego and a
 partner MLP on the observations, actions sampled on the device, episode statistics; one
 hipGraph per step block) through ``OvercookedVecEnv``; ``--policy fused`` (default) evaluates both
