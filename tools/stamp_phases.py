@@ -2,7 +2,9 @@
 """Diagnostic: where one wave of k_multi_step spends its cycles (s_memtime stamps).
 Builds a -DOC_STAMPS specialised library (never shipped, never timed), runs a few hundred
 steps and prints the median cycle count of every phase.  GPU box only.
-    python tools/stamp_phases.py [n] [waves per 64 envs: 0 = the library's choice, 1, 4] [pairs | stats]"""
+    python tools/stamp_phases.py [n] [waves per 64 envs: 0 = the library's choice, 1, 4] [pairs | stats | rng]
+(pairs: actions as [n][2] pairs; stats: rows + in-kernel episode statistics; rng: ego pairs + the
+in-kernel random partner + statistics -- what OvercookedVecEnv.step_tensors launches)"""
 import os
 import sys
 
@@ -23,7 +25,7 @@ def main():
     env = BatchedOvercooked("open-divider_tomato", num_agents=2, num_envs=n, max_num_timesteps=500,
                             num_communication=2, auto_reset=True, specialize_level=True,
                             waves_per_64=int(sys.argv[2]) if len(sys.argv) > 2 else 0,
-                            episode_stats=len(sys.argv) > 3 and sys.argv[3] == "stats")   # rows + statistics: general variant
+                            episode_stats=len(sys.argv) > 3 and sys.argv[3] in ("stats", "rng"))   # rows + statistics: the options variant
     sp = env.launch_waves(general=len(sys.argv) > 3)    # waves per 64 envs (4 = split launch): the kernel writes one record per wave
     waves = (n + 63) // 64 * sp
     dbg = torch.zeros((waves, 16), dtype=torch.int64, device="cuda")
@@ -31,10 +33,15 @@ def main():
     gen = torch.Generator(device="cuda").manual_seed(1)
     hi = torch.tensor([4, 2, 4, 2], device="cuda").view(4, 1)
     rows = []
-    pairs = len(sys.argv) > 3 and sys.argv[3] == "pairs"     # the general variant: actions as [n][2] pairs
+    pairs = len(sys.argv) > 3 and sys.argv[3] == "pairs"     # the options variant: actions as [n][2] pairs
+    rng_mode = len(sys.argv) > 3 and sys.argv[3] == "rng"
+    rng = torch.randint(0, 2 ** 31 - 1, (n,), generator=gen, device="cuda", dtype=torch.int32)
+    played = torch.zeros((2, n), dtype=torch.int32, device="cuda")
     for k in range(300):
         a = (torch.rand((4, n), generator=gen, device="cuda") * hi).to(torch.int32)
-        if pairs:
+        if rng_mode:
+            env.multi_step(a, ego_pairs=a[0:2].T.contiguous(), alt_rng=rng, alt_played=played)
+        elif pairs:
             env.multi_step(None, ego_pairs=a[0:2].T.contiguous(), alt_pairs=a[2:4].T.contiguous())
         else:
             env.multi_step(a)
