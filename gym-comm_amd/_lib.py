@@ -15,7 +15,7 @@ SYMBOLS = ["oc_abi_version", "oc_last_error", "oc_level_create", "oc_level_destr
            "oc_level_spec_source", "oc_is_specialized", "oc_level_subtask_info",
            "oc_metrics_slots", "oc_state_words", "oc_obs_rows", "oc_reset", "oc_step", "oc_obs",
            "oc_obs_image", "oc_image_words", "oc_multi_step", "oc_multi_step_waves", "oc_random_actions",
-           "oc_timeline_begin"]
+           "oc_timeline_begin", "oc_multi_step_prepare", "oc_call_launch", "oc_call_destroy"]
 
 
 class ObsCfg(ctypes.Structure):
@@ -105,9 +105,15 @@ def _declare(L):
     L.oc_multi_step_waves.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
     L.oc_multi_step_waves.restype = ctypes.c_int32
     L.oc_timeline_begin.argtypes = [vp, ctypes.c_int64, ctypes.c_int64]
+    L.oc_multi_step_prepare.argtypes = [vp, vp, vp, vp, ctypes.POINTER(WrapCfg), vp, vp, vp, vp, vp,
+                                        ctypes.c_int32, vp, vp, vp, ctypes.POINTER(StepOpts), ctypes.c_int64,
+                                        ctypes.POINTER(vp)]
+    L.oc_call_launch.argtypes = [vp, vp, ctypes.c_int32, vp]
+    L.oc_call_destroy.argtypes = [vp]
     for f in ("oc_level_create", "oc_level_destroy", "oc_level_spec_source", "oc_level_subtask_info",
               "oc_reset", "oc_step",
-              "oc_obs", "oc_obs_image", "oc_multi_step", "oc_random_actions", "oc_timeline_begin"):
+              "oc_obs", "oc_obs_image", "oc_multi_step", "oc_random_actions", "oc_timeline_begin",
+              "oc_multi_step_prepare", "oc_call_launch", "oc_call_destroy"):
         getattr(L, f).restype = ctypes.c_int
     if L.oc_abi_version() != ABI_VERSION:
         raise OcError("liboc_hip.so ABI version mismatch")

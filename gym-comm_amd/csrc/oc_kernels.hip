@@ -263,6 +263,25 @@ struct oc_level {
   int device;
 };
 
+// A prepared oc_multi_step (oc_multi_step_prepare): every argument by value
+struct oc_call {
+  const oc_level *lv;
+  int32_t *state, *comm;
+  const int32_t *actions;
+  oc_wrap_cfg cfg;
+  void *obs;
+  double *timestep, *reward;
+  int32_t *done, *sparse;
+  int32_t auto_reset;
+  int64_t *metrics;
+  const int32_t *placement;
+  uint32_t *rng;
+  oc_step_opts opts;
+  oc_step_policy pol[2];
+  bool has_pol;
+  int64_t n;
+};
+
 namespace {
 
 thread_local char g_err[256] = "";
@@ -2966,6 +2985,43 @@ int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, const int
 #endif
 #undef OC_MS_SPLIT
 #undef OC_MS_X
+}
+
+int oc_multi_step_prepare(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
+                          const oc_wrap_cfg *cfg, void *obs, double *timestep, double *reward, int32_t *done,
+                          int32_t *sparse, int32_t auto_reset, int64_t *metrics, const int32_t *placement,
+                          uint32_t *rng, const oc_step_opts *opts, int64_t n, oc_call_t **out) {
+  if (!out || !lv || !cfg) return fail(OC_E_BADARG, "oc_multi_step_prepare: bad argument");
+  oc_call *c = new (std::nothrow) oc_call();
+  if (!c) return fail(OC_E_BADARG, "oc_multi_step_prepare: out of memory");
+  c->lv = lv, c->state = state, c->comm = comm, c->actions = actions, c->cfg = *cfg, c->obs = obs;
+  c->timestep = timestep, c->reward = reward, c->done = done, c->sparse = sparse, c->auto_reset = auto_reset;
+  c->metrics = metrics, c->placement = placement, c->rng = rng, c->n = n;
+  memset(&c->opts, 0, sizeof(c->opts));
+  if (opts) c->opts = *opts;
+  c->has_pol = c->opts.policy != nullptr;
+  if (c->has_pol) {   // (a host array of the caller: copied, so that it need not outlive this call)
+    c->pol[0] = c->opts.policy[0], c->pol[1] = c->opts.policy[1];
+    c->opts.policy = c->pol;
+  }
+  *out = c;
+  return OC_OK;
+}
+
+int oc_call_launch(const oc_call_t *c, const void *ego_pairs, int32_t pairs_int64, void *stream) {
+  if (!c) return fail(OC_E_BADARG, "oc_call_launch: null call");
+  oc_step_opts o = c->opts;
+  if (ego_pairs) {
+    o.ego_pairs = (const int32_t *)ego_pairs;
+    o.pairs_int64 = pairs_int64;
+  }
+  return oc_multi_step(c->lv, c->state, c->comm, c->actions, &c->cfg, c->obs, c->timestep, c->reward, c->done,
+                       c->sparse, c->auto_reset, c->metrics, c->placement, c->rng, &o, c->n, stream);
+}
+
+int oc_call_destroy(oc_call_t *c) {
+  delete c;
+  return OC_OK;
 }
 
 int oc_timeline_begin(uint64_t *records, int64_t count, int64_t stride) {

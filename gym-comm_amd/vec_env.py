@@ -740,9 +740,13 @@ class OvercookedVecEnv(_VecEnvBase):
         pt = self.partner
         if self._use_graph or self.terminal_obs or not getattr(pt, "in_kernel", False) or hasattr(pt, "update"):
             return False
+        rng = pt.rng_state(self.num_envs).data_ptr()
         return {"act": self._act.data_ptr(), "played": self._act[2:4].data_ptr(),
-                "rng": pt.rng_state(self.num_envs).data_ptr(), "obs": self._obs_tensors(0),
-                "pair_shape": torch.Size((self.num_envs, 2)), "dev": self._b._dev_index}
+                "rng": rng, "obs": self._obs_tensors(0),
+                "pair_shape": torch.Size((self.num_envs, 2)), "dev": self._b._dev_index,
+                # the prepared call (include/oc_hip.h: oc_multi_step_prepare): everything but the ego's pairs fixed
+                "launch": self._b.prepare_multi_step(self._act.data_ptr(), alt_rng_ptr=rng,
+                                                     alt_played_ptr=self._act[2:4].data_ptr(), auto_reset=True)}
 
     def _capture(self, fn, players=(), repeat=1):
         """`repeat` calls of fn() as one hipGraph.  One eager warm-up call first (module loads,
@@ -822,7 +826,7 @@ class OvercookedVecEnv(_VecEnvBase):
                     ea = self._ego_pairs
                 ego_ptr = ea.data_ptr()
                 i64 = ea.dtype is torch.int64
-            b.multi_step_raw(f["act"], ego_ptr, None, f["rng"], f["played"], 1, ego_ptr is not None and i64)
+            f["launch"](ego_ptr, ego_ptr is not None and i64)
             self._version += 1
             self._last_terminal = None
             return f["obs"], b.shaped_reward, b.done

@@ -255,6 +255,21 @@ OC_API int oc_multi_step(const oc_level_t *lv, int32_t *state, int32_t *comm, co
                   const int32_t *placement, uint32_t *rng, const oc_step_opts *opts,
                   int64_t n, void *stream);
 
+/* A PREPARED oc_multi_step for callers that make the same call every step with, at most, another
+ * ego-action tensor (OvercookedVecEnv.step_tensors: a Python caller pays ~0.3 us per argument it has to
+ * convert; 17 of them were most of the 5.7 us a one-launch step cost on the host).  prepare() copies
+ * every argument BY VALUE (cfg, opts and opts.policy included; the device pointers must stay valid);
+ * launch() = oc_multi_step with those arguments, `ego_pairs` (if not NULL, with `pairs_int64`)
+ * replacing opts.ego_pairs for this launch only.  Same checks, same kernels, same results. */
+typedef struct oc_call oc_call_t;
+OC_API int oc_multi_step_prepare(const oc_level_t *lv, int32_t *state, int32_t *comm, const int32_t *actions,
+                                 const oc_wrap_cfg *cfg, void *obs, double *timestep, double *reward,
+                                 int32_t *done, int32_t *sparse, int32_t auto_reset, int64_t *metrics,
+                                 const int32_t *placement, uint32_t *rng, const oc_step_opts *opts, int64_t n,
+                                 oc_call_t **out);
+OC_API int oc_call_launch(const oc_call_t *call, const void *ego_pairs, int32_t pairs_int64, void *stream);
+OC_API int oc_call_destroy(oc_call_t *call);
+
 /* Waves per 64 envs oc_multi_step WILL LAUNCH for a batch of n envs given the caller's hint
  * (oc_step_opts.waves_per_64) and the variant the call selects -- general_variant != 0: any of
  * oc_step_opts' action sources / episode statistics / policy, or a non-standard wrapper

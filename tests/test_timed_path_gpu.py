@@ -233,3 +233,48 @@ def test_timeline_build_records_every_launch_and_steps_identically():
     first, last = start.min(axis=1), issue.max(axis=1)
     assert (first[1:] >= last[:-1]).all()                    # launches of one stream do not overlap
     assert ((last - first) < 100000).all()                   # < 1 ms at 100 MHz
+
+
+def test_prepared_call_steps_like_the_full_call():
+    """include/oc_hip.h: oc_multi_step_prepare / oc_call_launch = oc_multi_step with the arguments
+    fixed once (the foreign call OvercookedVecEnv.step_tensors makes per step).  Two batches from the
+    same seed, one stepped through ``multi_step`` and one through prepared calls -- action rows, and
+    int64 ego pairs beside the kernel's own partner draw -- must hold the same bytes after every step."""
+    from gym_comm_amd.batched import BatchedOvercooked
+    n, K, T = 4096 + 37, 90, 40
+    mk = lambda: BatchedOvercooked("open-divider_tomato", num_envs=n, max_num_timesteps=T, num_communication=2,
+                                   fow_radius=2, seed=3, episode_stats=True)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    rows = torch.randint(0, 2, (K, 4, n), generator=gen, device="cuda", dtype=torch.int32)
+    rows[:, 0] = torch.randint(0, 4, (K, n), generator=gen, device="cuda", dtype=torch.int32)
+    rows[:, 2] = torch.randint(0, 4, (K, n), generator=gen, device="cuda", dtype=torch.int32)
+    pairs = torch.stack([rows[:, 0], rows[:, 1]], dim=2).to(torch.int64).contiguous()        # [K][n][2]
+    same = lambda a, b: all(torch.equal(getattr(a, f), getattr(b, f)) for f in
+                            ("state", "comm", "obs", "done", "metrics", "ep_return", "ep_length")) and \
+        torch.equal(a.shaped_reward.view(torch.int64), b.shaped_reward.view(torch.int64)) and \
+        torch.equal(a.timestep.view(torch.int64), b.timestep.view(torch.int64))
+    # (1) action rows: the prepared call reads the SAME buffer every launch
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    buf = torch.empty((4, n), dtype=torch.int32, device="cuda")
+    launch = b.prepare_multi_step(buf.data_ptr())
+    for k in range(K):
+        a.multi_step(rows[k].contiguous())
+        buf.copy_(rows[k])
+        launch()
+        assert same(a, b), k
+    assert int(a.metrics.sum()) > 0 and int(a.done.sum()) >= 0
+    # (2) int64 ego pairs per launch + the kernel's own partner draw
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    rng_a = torch.arange(n, dtype=torch.int32, device="cuda") * 7 + 1
+    rng_b = rng_a.clone()
+    played_a = torch.zeros((2, n), dtype=torch.int32, device="cuda")
+    played_b = torch.zeros_like(played_a)
+    launch = b.prepare_multi_step(0, alt_rng_ptr=rng_b.data_ptr(), alt_played_ptr=played_b.data_ptr())
+    for k in range(K):
+        a.multi_step(ego_pairs=pairs[k], alt_rng=rng_a, alt_played=played_a)
+        launch(pairs[k].data_ptr(), True)
+        assert same(a, b) and torch.equal(played_a, played_b) and torch.equal(rng_a, rng_b), k
+    # a NULL call is refused, not dereferenced
+    assert a._L.oc_call_launch(None, None, 0, None) == -1      # OC_E_BADARG

@@ -72,7 +72,7 @@ PROBE(p_nop, "s_nop 0", 1)
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(sink + 1024, 0, 1 << 20, 0x00020000); \
     unsigned long long t0, t1;                                                                     \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");                     \
-    asm volatile(".rept 32\n" BODY "\n.endr" : "+v"(v), "+v"(q) : "v"(off), "s"(r) : "memory");   \
+    asm volatile("s_mov_b32 s20, 0\n.rept 32\n" BODY "\n.endr" : "+v"(v), "+v"(q) : "v"(off), "s"(r) : "memory", "s20");   \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");                     \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
     if (threadIdx.x == 0) out[0] = (t1 - t0) * (REPS * LOOPS) / 32;                                \
@@ -83,8 +83,29 @@ MEMPROBE(m_store_dword_sc1, "buffer_store_dword %0, %2, %3, 0 offen sc1", 1)
 MEMPROBE(m_store_dword, "buffer_store_dword %0, %2, %3, 0 offen", 1)
 MEMPROBE(m_store_dwordx4_sc1, "buffer_store_dwordx4 %1, %2, %3, 0 offen sc1", 1)
 MEMPROBE(m_store_byte_sc1, "buffer_store_byte %0, %2, %3, 0 offen sc1", 1)
+// the row stores of the step kernels: the row offset in a FRESHLY written scalar (soffset), as the kernels
+// form it (s_mul_i32 per row), against the same offset added into the lane's VGPR offset
+MEMPROBE(m_store_soffset_fresh, "s_add_u32 s20, s20, 64\n buffer_store_dword %0, %2, %3, s20 offen sc1", 2)
+MEMPROBE(m_store_soffset_fresh_valu2, "s_add_u32 s20, s20, 64\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n buffer_store_dword %0, %2, %3, s20 offen sc1", 4)
+MEMPROBE(m_store_soffset_early, "buffer_store_dword %0, %2, %3, s20 offen sc1\n s_add_u32 s20, s20, 64", 2)
+MEMPROBE(m_store_voffset_fresh, "v_add_u32 %0, 64, %0\n buffer_store_dword %0, %0, %3, 0 offen sc1", 2)
 MEMPROBE(m_store_dword_sc1_valu3, "buffer_store_dword %0, %2, %3, 0 offen sc1\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0", 4)
 MEMPROBE(m_store_dword_sc1_valu7, "buffer_store_dword %0, %2, %3, 0 offen sc1\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0", 8)
+
+// the same row stores from FOUR waves of one workgroup at once (one per SIMD of a CU, as a split launch has
+// them): do the four share one address / store pipe?
+__global__ void __launch_bounds__(256) m4_store_rows(unsigned long long *out, int *sink, int seed) {
+  int v = threadIdx.x + seed, off = (threadIdx.x & 63) * 4 + (threadIdx.x >> 6) * 65536;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(sink + 1024, 0, 1 << 20, 0x00020000);
+  unsigned long long t0, t1;
+  __syncthreads();
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  asm volatile("s_mov_b32 s20, 0\n.rept 32\n s_add_u32 s20, s20, 1024\n buffer_store_dword %0, %1, %2, s20 offen sc1\n.endr" : "+v"(v) : "v"(off), "s"(r) : "memory", "s20");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = (t1 - t0);
+  sink[threadIdx.x] = v;
+}
 
 #define RUN(NAME)                                                                               \
   do {                                                                                          \
@@ -126,7 +147,25 @@ int main() {
   RUN(m_store_dword);
   RUN(m_store_dwordx4_sc1);
   RUN(m_store_byte_sc1);
+  RUN(m_store_soffset_fresh);
+  RUN(m_store_soffset_fresh_valu2);
+  RUN(m_store_soffset_early);
+  RUN(m_store_voffset_fresh);
   RUN(m_store_dword_sc1_valu3);
   RUN(m_store_dword_sc1_valu7);
+  for (int waves = 1; waves <= 4; waves++) {
+    double best = 1e30;
+    for (int r = 0; r < 5; r++) {
+      hipLaunchKernelGGL(m4_store_rows, dim3(1), dim3(64 * waves), 0, 0, out, sink, r);
+      hipDeviceSynchronize();
+      unsigned long long h[4];
+      hipMemcpy(h, out, 32, hipMemcpyDeviceToHost);
+      unsigned long long mx = 0;
+      for (int w = 0; w < waves; w++) mx = h[w] > mx ? h[w] : mx;
+      if ((double)mx < best) best = (double)mx;
+    }
+    printf("32 row stores (+ s_add each) per wave, %d wave(s) of one workgroup at once: slowest wave %.0f cycles = %.1f per store\n",
+           waves, best, best / 32);
+  }
   return 0;
 }
