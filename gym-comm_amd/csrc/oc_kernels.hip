@@ -1840,32 +1840,43 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
     typedef int v2i __attribute__((ext_vector_type(2)));
     typedef int v4i __attribute__((ext_vector_type(4)));
     // raw words as they are loaded (no shuffling here: a move of a loaded word is a wait for it):
-    // int64 pairs {move lo, move hi, comm lo, comm hi}; int32 pairs and rows {move, comm, -, -}
+    // int64 pairs {move lo, move hi, comm lo, comm hi}; int32 pairs and rows {move, comm}.
+    // XO != 0: NO BRANCH over the sources.  Per player ONE 16-byte load serves both [n][2] forms --
+    // int64 pairs (lane offset 16 i: the pair), int32 pairs (8 i: the pair and the next env's) -- two
+    // dword loads serve the rows and one the partner's PCG32 word, each through a buffer descriptor
+    // whose length is 0 when the form is not in use: a load past the end of its buffer returns 0 and
+    // touches no memory.  (A chain of uniform branches, one
+    // load per arm, is laid out as consecutive `if`s with flag words and a value merged at every
+    // join; the wait-count pass follows EVERY path through them, found a register written on one path
+    // -- a zero default, a copy for the merge, an address formed in a destination register -- with a
+    // load outstanding on another, and put an s_waitcnt vmcnt(0) into the common path in front of the
+    // episode statistics' loads: a second memory round trip for int32 pairs + statistics and for the
+    // fused policies.)
     v4i eq = {0, 0, 0, 0}, aq = {0, 0, 0, 0};
-    if (ego_from_pairs && pairs64) {   // int64 pairs (a torch argmax / sample as it comes)
-      const Rows pr(ego_src_, n_, 1, i, 16);
-      eq = (v4i)__builtin_amdgcn_raw_buffer_load_b128(pr.rsrc, pr.voff, 0, 0);
-    } else if (ego_from_pairs) {
-      const Rows pr(ego_src_, n_, 1, i, 8);
-      const v2i q = (v2i)__builtin_amdgcn_raw_buffer_load_b64(pr.rsrc, pr.voff, 0, 0);
-      eq.x = q.x, eq.y = q.y;
-    } else {
-      const Rows ac(actions_, n_, 4, i);
-      eq.x = ac.ld(0), eq.y = ac.ld(1);
-    }
+    v2i er = {0, 0}, ar = {0, 0};
     uint32_t alt_rs = 0;
-    if (alt_from_rng) {
-      alt_rs = (uint32_t)Rows(alt_src_, n_, 1, i).ld(0);
-    } else if (alt_from_pairs && pairs64) {
-      const Rows pr(alt_src_, n_, 1, i, 16);
-      aq = (v4i)__builtin_amdgcn_raw_buffer_load_b128(pr.rsrc, pr.voff, 0, 0);
-    } else if (alt_from_pairs) {
-      const Rows pr(alt_src_, n_, 1, i, 8);
-      const v2i q = (v2i)__builtin_amdgcn_raw_buffer_load_b64(pr.rsrc, pr.voff, 0, 0);
-      aq.x = q.x, aq.y = q.y;
+    if constexpr (XO != 0) {
+      const auto desc = [&](const void *base, bool on, int bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, on ? bytes : 0, 0x00020000);
+      };
+      const int sh = pairs64 ? 4 : 3;
+      const __amdgpu_buffer_rsrc_t d_er = desc(actions_, !ego_from_pairs, (int)n_ * 16),
+                                   d_ar = desc(actions_, !alt_from_pairs && !alt_from_rng, (int)n_ * 16),
+                                   d_eq = desc(ego_src_, ego_from_pairs, (int)n_ << sh),
+                                   d_aq = desc(alt_src_, alt_from_pairs && !alt_from_rng, (int)n_ << sh),
+                                   d_rs = desc(alt_src_, alt_from_rng, (int)n_ * 4);
+      const int off4 = i << 2, offq = i << sh, row = (int)n_ * 4;
+      eq = (v4i)__builtin_amdgcn_raw_buffer_load_b128(d_eq, offq, 0, 0);
+      aq = (v4i)__builtin_amdgcn_raw_buffer_load_b128(d_aq, offq, 0, 0);
+      alt_rs = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(d_rs, off4, 0, 0);
+      er.x = __builtin_amdgcn_raw_buffer_load_b32(d_er, off4, 0, 0);
+      er.y = __builtin_amdgcn_raw_buffer_load_b32(d_er, off4, row, 0);
+      ar.x = __builtin_amdgcn_raw_buffer_load_b32(d_ar, off4, 2 * row, 0);
+      ar.y = __builtin_amdgcn_raw_buffer_load_b32(d_ar, off4, 3 * row, 0);
     } else {
       const Rows ac(actions_, n_, 4, i);
-      aq.x = ac.ld(2), aq.y = ac.ld(3);
+      er.x = ac.ld(0), er.y = ac.ld(1);
+      ar.x = ac.ld(2), ar.y = ac.ld(3);
     }
     if constexpr (!LDS) tb = stage_tables<false>(p.tables, p.n16, p.quot_bytes);
     // the output pointers are needed hundreds of instructions from here, where the compiler
@@ -1902,16 +1913,24 @@ __device__ __forceinline__ void multi_step_body(int32_t *const state_, const int
       if (L.nscatter() != 0 && p.rng != nullptr) place_rs = (uint32_t)Rows(p.rng, n_, 1, i).ld(0);   // uniform
       // (the raw action words pass THROUGH this statement: the optimiser otherwise threads the decode
       // below back into the branch that issued each load, and its wait in front of the later loads)
-      if constexpr (XO != 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : "+v"(alt_rs), "+v"(eq), "+v"(aq)::"memory");
+      if constexpr (XO != 0)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : "+v"(eq), "+v"(aq), "+v"(er), "+v"(ar), "+v"(alt_rs)::"memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     } else if constexpr (XO != 0) {
-      asm volatile("" : "+v"(alt_rs), "+v"(eq), "+v"(aq));
+      asm volatile("" : "+v"(eq), "+v"(aq), "+v"(er), "+v"(ar), "+v"(alt_rs));
     }
-    // DECODE PHASE (every load is out; a split workgroup is past its barrier)
-    int ego_mv = eq.x, ego_cm = eq.y, alt_mv = aq.x, alt_cm = aq.y;
-    if (pairs64) {   // uniform: an int64 outside int32 is no valid index
-      if (ego_from_pairs) ego_mv = (eq.y == (eq.x >> 31)) ? eq.x : -1, ego_cm = (eq.w == (eq.z >> 31)) ? eq.z : -1;
-      if (alt_from_pairs && !alt_from_rng) alt_mv = (aq.y == (aq.x >> 31)) ? aq.x : -1, alt_cm = (aq.w == (aq.z >> 31)) ? aq.z : -1;
+    // DECODE PHASE (every load is out; a split workgroup is past its barrier: branches are free of
+    // waits here).  A form not in use read 0; an int64 outside int32 is no valid index: -1.
+    int ego_mv = er.x, ego_cm = er.y, alt_mv = ar.x, alt_cm = ar.y;
+    if constexpr (XO != 0) {
+      const auto narrow = [](int lo, int hi) { return lo | ~p_eq_any(hi, lo >> 31); };
+      if (pairs64) {   // uniform
+        ego_mv |= narrow(eq.x, eq.y), ego_cm |= narrow(eq.z, eq.w);
+        alt_mv |= narrow(aq.x, aq.y), alt_cm |= narrow(aq.z, aq.w);
+      } else {
+        ego_mv |= eq.x, ego_cm |= eq.y;
+        alt_mv |= aq.x, alt_cm |= aq.y;
+      }
     }
     if (alt_from_rng) {   // uniform: the partner's draw, two steps of the env's PCG32 stream
       alt_mv = (int)__umulhi(pcg32(alt_rs), 4u);
