@@ -107,6 +107,29 @@ __global__ void __launch_bounds__(256) m4_store_rows(unsigned long long *out, in
   sink[threadIdx.x] = v;
 }
 
+
+// latency of the scalar time reads the TIMELINE build uses (and of a scalar kernarg-style load, for
+// scale): s_memtime; <op>; s_waitcnt lgkmcnt(0); s_memtime -- minus the same with no <op>
+__global__ void smem_latency(unsigned long long *out, const int *src) {
+  unsigned long long t0, t1, t2, t3, t4, x;
+  int y;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(y) : "s"(src) : "memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3)::"memory");
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(y) : "s"(src) : "memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t4)::"memory");
+  if (threadIdx.x == 0) {
+    out[0] = t1 - t0;   // one s_memtime round trip
+    out[1] = t2 - t1;   // s_memrealtime + s_memtime
+    out[2] = t3 - t2;   // s_load_dword (cold) + s_memtime
+    out[3] = t4 - t3;   // s_load_dword (scalar-cache hit) + s_memtime
+    out[4] = x + y;
+  }
+}
+
 #define RUN(NAME)                                                                               \
   do {                                                                                          \
     double best = 1e30;                                                                         \
@@ -166,6 +189,18 @@ int main() {
     }
     printf("32 row stores (+ s_add each) per wave, %d wave(s) of one workgroup at once: slowest wave %.0f cycles = %.1f per store\n",
            waves, best, best / 32);
+  }
+  {
+    unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    for (int r = 0; r < 5; r++) {
+      hipLaunchKernelGGL(smem_latency, dim3(1), dim3(64), 0, 0, out, sink);
+      hipDeviceSynchronize();
+      unsigned long long h[5];
+      hipMemcpy(h, out, 40, hipMemcpyDeviceToHost);
+      for (int k = 0; k < 4; k++) best[k] = h[k] < best[k] ? h[k] : best[k];
+    }
+    printf("scalar time reads, issue -> result (shader cycles): s_memtime %llu, s_memrealtime %llu, s_load_dword cold %llu, hit %llu\n",
+           best[0], best[1] - best[0], best[2] - best[0], best[3] - best[0]);
   }
   return 0;
 }
