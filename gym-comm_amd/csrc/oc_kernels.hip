@@ -2757,7 +2757,10 @@ int oc_level_subtask_info(const int32_t *b, int32_t n_words, int32_t *slot, int3
   return OC_OK;
 }
 
-int64_t oc_metrics_slots(int64_t n) { return n <= 0 ? 0 : (n + 63) / 64; }
+// One slot per wave of 64 envs, rounded up to whole workgroups of four waves: under a forced
+// 128- / 256-thread workgroup (OC_LAUNCH=block=...) the last workgroup may hold waves without an env,
+// and those add zeros to THEIR slot.
+int64_t oc_metrics_slots(int64_t n) { return n <= 0 ? 0 : (n + 255) / 256 * 4; }
 int32_t oc_state_words(const oc_level_t *lv) {
   return lv ? lv->hdr.A + lv->hdr.M + 2 + (lv->hdr.has_dup ? 2 : 0) : 0;
 }

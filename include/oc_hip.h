@@ -188,7 +188,7 @@ OC_API int oc_is_specialized(void);
  * The completed_subtasks observation rows are already in the blob's order.  Host only. */
 OC_API int oc_level_subtask_info(const int32_t *blob, int32_t n_words, int32_t *slot, int32_t *goal_index,
                                  int32_t *dup);
-OC_API int64_t oc_metrics_slots(int64_t n);                         /* ceil(n / 64) */
+OC_API int64_t oc_metrics_slots(int64_t n);                         /* 4 * ceil(n / 256): a slot per wave of 64 envs, whole workgroups */
 OC_API int32_t oc_state_words(const oc_level_t *lv);                 /* A + M + 2 */
 OC_API int32_t oc_obs_rows(const oc_level_t *lv, int32_t num_comm);  /* 22 + S + 2C */
 
